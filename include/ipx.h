@@ -1,0 +1,134 @@
+/*
+ * ipx.h — C ABI of the MI355X (gfx950) exact inner-product search engine.
+ *
+ * This is the drop-in boundary for the retrieval hot path of
+ * tevatron.faiss_retriever (reference paths are relative to /root/reference/src):
+ * each entry point below replaces one call the reference makes into faiss.
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a non-zero ipx_status on failure;
+ *     ipx_last_error() then returns a thread-local, human-readable message.
+ *     Nothing here aborts the process or throws across the boundary.
+ *   - `on_device` != 0 means the data pointers are device (HBM) pointers on the
+ *     index's GPU; 0 means host pointers (the library stages the copies itself).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     Calls with host pointers are synchronous; calls with device pointers are
+ *     stream-ordered and return without synchronising.
+ *   - doc ids are row numbers in insertion order (faiss IndexFlat semantics) plus
+ *     the index's id_base; empty result slots hold id -1 and score -FLT_MAX.
+ *   - result order: score descending, ties by ascending id (deterministic;
+ *     faiss 1.7.2 leaves the order of exactly-equal scores unspecified).
+ */
+#ifndef IPX_H_
+#define IPX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ipx_index ipx_index;
+
+enum ipx_status {
+    IPX_OK = 0,
+    IPX_ERR_ARG = 1,     /* bad argument (dimension mismatch, k out of range, null pointer) */
+    IPX_ERR_HIP = 2,     /* a HIP runtime call failed */
+    IPX_ERR_NOMEM = 3,   /* device or host allocation failed */
+    IPX_ERR_STATE = 4,   /* internal invariant violated (candidate queue overflow) */
+    IPX_ERR_IO = 5       /* file could not be written */
+};
+
+enum ipx_dtype { IPX_F32 = 0, IPX_F16 = 1, IPX_BF16 = 2 };
+
+/* Largest k a single search / merge call accepts. */
+#define IPX_MAX_K 2048
+
+/* Thread-local message for the last failing call on this thread. */
+const char* ipx_last_error(void);
+
+/* Library build tag, e.g. "ipx 0.1 gfx950". */
+const char* ipx_version(void);
+
+/* Number of visible HIP devices (0 when there is no GPU); never fails. */
+int ipx_device_count(void);
+
+/* Replaces faiss.IndexFlatIP(d)                       retriever.py:12
+ * Creates an empty flat inner-product index of dimension d on GPU `device`. */
+int ipx_create(int d, int device, ipx_index** out);
+
+/* Releases the index and all device memory it owns (object GC in the reference). */
+int ipx_destroy(ipx_index* idx);
+
+/* index.d / index.ntotal of the faiss object          retriever.py:13 (self.index) */
+int     ipx_dim(const ipx_index* idx);
+int64_t ipx_ntotal(const ipx_index* idx);
+
+/* Pre-sizes device storage for n rows in total (optional; add grows on demand). */
+int ipx_reserve(ipx_index* idx, int64_t n);
+
+/* Offset added to every returned row id (row-sharded multi-GPU search; the
+ * reference gets global ids from per-shard lookup tables, docs/retrieval.md:34-45). */
+int ipx_set_id_base(ipx_index* idx, int64_t id_base);
+
+/* Replaces index.add(p_reps)                          retriever.py:16
+ * Appends n rows of dimension d. `rows` is C-contiguous [n, d] of `dtype`
+ * (ipx_dtype); f16/bf16 rows are widened to fp32 on the device, which is what
+ * `p_reps.astype('float32')` does on the host in __main__.py:79. */
+int ipx_add(ipx_index* idx, const void* rows, int64_t n, int dtype, int on_device, void* stream);
+
+/* Replaces index.search(q_reps, k)                    retriever.py:19
+ * q: fp32 [nq, d]; out_D: fp32 [nq, k]; out_I: int64 [nq, k]. */
+int ipx_search(ipx_index* idx, const float* q, int64_t nq, int k,
+               float* out_D, int64_t* out_I, int on_device, void* stream);
+
+/* MURAL multi-aspect query, fused on the device before the scan:
+ *   q[i] = sum_a w[i][a] * aspect_emb[i][a][:]        modeling/mul_grain.py:97-110
+ * aspect_emb: fp32 [nq, A, d]; w: fp32 [nq, A]. If w_is_logits != 0 the weights are
+ * soft-maxed over a first (mul_grain.py:103-105). The result equals ipx_search on
+ * the pre-fused query vectors (inner product is linear in q). */
+int ipx_search_aspect(ipx_index* idx, const float* aspect_emb, const float* w, int A,
+                      int w_is_logits, int64_t nq, int k,
+                      float* out_D, int64_t* out_I, int on_device, void* stream);
+
+/* Replaces faiss.ResultHeap(nq,k).add_result(-D_s, I_s) for s in shards; finalize()
+ *                                                      reducer.py:15-18
+ * D: fp32 [S, nq, k_in], I: int64 [S, nq, k_in] (one block per shard, ids already
+ * global, id -1 marks an empty slot). Writes the global top k_out per query, sorted
+ * (score desc, id asc), padded with (-FLT_MAX, -1). `device` selects the GPU. */
+int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in, int k_out,
+                   float* out_D, int64_t* out_I, int on_device, int device, void* stream);
+
+/* Stream-ordered (on_device) searches return before the kernels finish; this waits for
+ * `stream` and reports an invariant violation the kernels flagged (IPX_ERR_STATE), if any.
+ * Host-pointer searches do this themselves. */
+int ipx_check(ipx_index* idx, void* stream);
+
+/* Timing of the kernels of the most recent search call on this index, measured with
+ * HIP events on the stream they were launched on. ipx_set_timing(idx,1) enables it.
+ * ipx_last_timing synchronises on the recorded events. Any output may be NULL. */
+int ipx_set_timing(ipx_index* idx, int enabled);
+int ipx_last_timing(ipx_index* idx, float* pack_ms, float* scan_ms, float* merge_ms);
+
+/* Launch geometry chosen by the most recent search: workgroups, corpus splits per
+ * query block, candidate-queue capacity. For bench / DESIGN.md bookkeeping. */
+int ipx_last_geometry(const ipx_index* idx, int* workgroups, int* splits, int* queue_cap);
+
+/* Replaces the Python loop of write_ranking            __main__.py:32-38
+ * Host-only. For each query i (in order) sorts its k hits by score descending (stable,
+ * like Python's sorted(..., reverse=True) on the score alone) and writes
+ *   f"{qid}\t{docid}\t{score}\n"
+ * where score is the float32 widened to double and printed with Python's repr(float).
+ * qids / docids are arrays of NUL-terminated UTF-8 strings: qids[nq], docids[nq*k]. */
+int ipx_write_ranking(const char* path, const char* const* qids, const char* const* docids,
+                      const float* scores, int64_t nq, int k);
+
+/* Python repr(float(np.float32(x))) into buf (>= 32 bytes). Returns the length. */
+int ipx_format_score(float x, char* buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPX_H_ */

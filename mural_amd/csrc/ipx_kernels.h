@@ -1,0 +1,411 @@
+// ipx_kernels.h — device kernels of the gfx950 exact inner-product search engine.
+//
+// Replaces the arithmetic faiss does for tevatron.faiss_retriever
+// (IndexFlat::search -> knn_inner_product + heap top-k, called from
+// src/tevatron/faiss_retriever/retriever.py:19, and ResultHeap in reducer.py:15-18).
+//
+// Data layout in HBM (chosen for the scan kernel, built once by pack_rows_kernel):
+//   rows are grouped in tiles of R rows (R = 128 for the corpus, 256 for a query block);
+//   a tile is cut along the feature axis into K-stages of 16 floats; one stage of one
+//   tile is a contiguous block  [R rows][4 chunks][4 floats]  (R*64 bytes), and the 16-byte
+//   chunk c of row r is stored at chunk slot  c ^ ((r >> 2) & 3).
+//   => a stage is copied HBM -> LDS by linear 1-KiB global_load_lds_dwordx4 pieces, and the
+//      ds_read_b128 operand reads of the MFMA loop are bank-conflict free (16 lanes of a
+//      read group hit 16 different 16-byte slots of the 256-byte bank row).
+//   d is zero-padded to a multiple of 16, the row count to a multiple of R.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <float.h>
+
+namespace ipx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BD = 128;       // corpus rows (docs) per score tile
+constexpr int BQ = 256;       // queries per workgroup
+constexpr int BK = 16;        // floats per K-stage
+constexpr int NTHREADS = 256; // 4 waves: 2 (docs) x 2 (queries), each 64 docs x 128 queries
+constexpr int STAGE_A_BYTES = BD * BK * 4;                 // 8 KiB
+constexpr int STAGE_B_BYTES = BQ * BK * 4;                 // 16 KiB
+constexpr int STAGE_BYTES = STAGE_A_BYTES + STAGE_B_BYTES; // 24 KiB
+constexpr int LDS_STATE_BYTES = 2 * BQ * 4;                // queue counters + thresholds
+
+// ---- order-preserving key for (score, row) pairs -------------------------------------------
+// key = ordered(score) << 32 | ~row : larger key = better hit (score desc, row asc).
+// ordered() maps float bits to unsigned so that unsigned order == float order; every real
+// score maps to a value > 0, so key 0 is the "empty slot" sentinel.
+__device__ __forceinline__ uint32_t f32_ordered(float x) {
+    uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_unordered(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ uint64_t make_key(float score, uint32_t row) {
+    return ((uint64_t)f32_ordered(score) << 32) | (uint32_t)(~row);
+}
+
+// LDS traffic inside one wave needs no s_barrier: the LDS unit executes a wave's DS
+// instructions in issue order. This only stops the compiler from moving or caching them.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Blocks b and b+8 share an XCD (and its L2). Give each XCD a contiguous run of logical
+// ids so that the workgroups of one query block sit behind one L2. Bijective for any G.
+__device__ __forceinline__ int xcd_remap(int b, int G) {
+    const int q = G >> 3, r = G & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+// ---- pack_rows: row-major [n, d] (f32 / f16 / bf16) -> tiled, padded, swizzled fp32 ----------
+// One thread per (row, 16-byte chunk). Rows [n, n_pad) and features [d, 16*nks) are zeros.
+// With A > 0 the source row is the aspect-fused query  sum_a w[r][a] * src[r][a][:]
+// (MURAL, modeling/mul_grain.py:97-110); with logits != 0 the weights are soft-maxed first.
+__device__ __forceinline__ float load_as_f32(const void* p, int dtype, int64_t i) {
+    if (dtype == 0) return ((const float*)p)[i];
+    if (dtype == 1) return __half2float(((const __half*)p)[i]);
+    return __uint_as_float(((uint32_t)((const uint16_t*)p)[i]) << 16);
+}
+
+__global__ void __launch_bounds__(256)
+pack_rows_kernel(const void* __restrict__ src, int dtype, int64_t n, int64_t n_pad, int d,
+                 float* __restrict__ dst, int64_t row0, int rows_per_tile, int nks,
+                 const float* __restrict__ w, int A, int logits) {
+    const int nchunks = nks * 4;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = gid / nchunks;
+    const int c = (int)(gid - r * nchunks);
+    if (r >= n_pad) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < n) {
+        const int k0 = c * 4;
+        if (A <= 0) {
+            const int64_t base = r * (int64_t)d;
+            if (dtype == 0 && (d & 3) == 0 && k0 + 3 < d) {
+                v = *(const f32x4*)((const float*)src + base + k0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k0 + e < d) v[e] = load_as_f32(src, dtype, base + k0 + e);
+            }
+        } else {
+            // aspect fusion: weights (optionally softmax of logits), then a fused-multiply-add
+            // chain over the aspects in index order.
+            float mx = -INFINITY, den = 0.f;
+            if (logits) {
+                for (int a = 0; a < A; ++a) mx = fmaxf(mx, w[r * A + a]);
+                for (int a = 0; a < A; ++a) den += expf(w[r * A + a] - mx);
+            }
+            for (int a = 0; a < A; ++a) {
+                float wa = w[r * A + a];
+                if (logits) wa = expf(wa - mx) / den;
+                const int64_t base = (r * A + a) * (int64_t)d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k0 + e < d) v[e] = fmaf(wa, load_as_f32(src, dtype, base + k0 + e), v[e]);
+            }
+        }
+    }
+    const int64_t R = row0 + r;
+    const int64_t tile = R / rows_per_tile;
+    const int rr = (int)(R - tile * rows_per_tile);
+    const int ks = c >> 2, pc = (c & 3) ^ ((rr >> 2) & 3);
+    float* o = dst + ((tile * nks + ks) * rows_per_tile + rr) * 16 + pc * 4;
+    *(f32x4*)o = v;
+}
+
+// ---- scan: fused fp32-MFMA score tiles + streaming per-query top-k ---------------------------
+struct ScanParams {
+    const float* Xp;     // packed corpus  [ntiles][nks][128][16]
+    const float* Qp;     // packed queries [nqb][nks][256][16]
+    uint64_t* cand;      // candidate queues [gridDim.x][256][cap] (keys)
+    float* outD;         // [nq][S][k]  sorted partial (or final, when S == 1) scores
+    int64_t* outI;       // [nq][S][k]  ids (id_base + row), -1 for empty slots
+    int* err;            // set to 1 if a queue would overflow (invariant violation)
+    int64_t N;           // rows in the index
+    int64_t id_base;
+    int nq, nks, k, cap, S, tps, ntiles;
+};
+
+// bitonic sort, descending, of P (power of two) 64-bit keys in LDS by one wave
+__device__ __forceinline__ void wave_sort_desc(uint64_t* keys, int P, int lane) {
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = lane; i < (P >> 1); i += 64) {
+                const int lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const uint64_t x = keys[lo], y = keys[hi];
+                if ((x < y) == desc) { keys[lo] = y; keys[hi] = x; }
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+// One wave reduces query `ql`'s queue to its best min(n, k) keys (sorted), updates the
+// threshold, and — on the final call — writes the sorted result row.
+__device__ __forceinline__ void compact_query(const ScanParams& p, uint64_t* scratch, int* cnts,
+                                              float* taus, uint64_t* queue, int ql, int lane,
+                                              bool final_pass, int64_t qglobal, int split) {
+    const int n = cnts[ql];
+    if (!final_pass && n <= p.k) return;
+    int P = 2;
+    while (P < n) P <<= 1;
+    for (int i = lane; i < P; i += 64) scratch[i] = (i < n) ? queue[i] : 0ull;
+    wave_lds_sync();
+    wave_sort_desc(scratch, P, lane);
+    const int m = n < p.k ? n : p.k;
+    if (!final_pass) {
+        for (int i = lane; i < m; i += 64) queue[i] = scratch[i];
+        if (lane == 0) {
+            cnts[ql] = m;
+            if (n >= p.k) taus[ql] = f32_unordered((uint32_t)(scratch[p.k - 1] >> 32));
+        }
+    } else {
+        float* oD = p.outD + ((size_t)qglobal * p.S + split) * p.k;
+        int64_t* oI = p.outI + ((size_t)qglobal * p.S + split) * p.k;
+        for (int i = lane; i < p.k; i += 64) {
+            if (i < m) {
+                const uint64_t key = scratch[i];
+                oD[i] = f32_unordered((uint32_t)(key >> 32));
+                oI[i] = p.id_base + (int64_t)(uint32_t)(~(uint32_t)key);
+            } else {
+                oD[i] = -FLT_MAX;
+                oI[i] = -1;
+            }
+        }
+    }
+    wave_lds_sync();
+}
+
+__device__ __forceinline__ void issue_stage(const ScanParams& p, char* buf, int64_t tile, int qb,
+                                            int ks, int wave, int lane) {
+    // A stage: 8 KiB contiguous, 2 x 1 KiB per wave; B stage: 16 KiB contiguous, 4 x 1 KiB per wave.
+    const char* ga = (const char*)p.Xp + ((size_t)tile * p.nks + ks) * STAGE_A_BYTES + wave * 2048 + lane * 16;
+    const char* gb = (const char*)p.Qp + ((size_t)qb * p.nks + ks) * STAGE_B_BYTES + wave * 4096 + lane * 16;
+    char* la = buf + wave * 2048;
+    char* lb = buf + STAGE_A_BYTES + wave * 4096;
+#define IPX_GLDS(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g), \
+                                                         (__attribute__((address_space(3))) void*)(l), 16, 0, 0)
+    IPX_GLDS(ga, la);
+    IPX_GLDS(ga + 1024, la + 1024);
+    IPX_GLDS(gb, lb);
+    IPX_GLDS(gb + 1024, lb + 1024);
+    IPX_GLDS(gb + 2048, lb + 2048);
+    IPX_GLDS(gb + 3072, lb + 3072);
+#undef IPX_GLDS
+}
+
+__global__ void __launch_bounds__(NTHREADS, 2)
+scan_f32_kernel(const ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [0, 2*STAGE_BYTES) : two K-stage buffers; the same bytes are the sort scratch of a
+    // compaction (4 waves x cap keys), which only runs when no stage is live.
+    const int scratch_bytes = 4 * p.cap * 8;
+    const int stage_region = scratch_bytes > 2 * STAGE_BYTES ? scratch_bytes : 2 * STAGE_BYTES;
+    int* cnts = (int*)(smem + stage_region);
+    float* taus = (float*)(smem + stage_region + BQ * 4);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wd = wave & 1, wq = wave >> 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = logical / p.S, split = logical - qb * p.S;
+    const int t0 = split * p.tps;
+    const int t1 = (t0 + p.tps < p.ntiles) ? t0 + p.tps : p.ntiles;
+
+    // thresholds: -FLT_MAX is faiss's heap neutral (scores must be > it to enter);
+    // +inf parks the padding queries of the last block.
+    cnts[tid] = 0;
+    taus[tid] = ((int64_t)qb * BQ + tid < p.nq) ? -FLT_MAX : INFINITY;
+
+    uint64_t* myqueues = p.cand + (size_t)blockIdx.x * BQ * p.cap;
+    uint64_t* scratch = (uint64_t*)smem + (size_t)wave * p.cap;
+
+    const int sw = (lane >> 2) & 3;
+    const int a_off = (wd * 64 + l31) * 64;     // byte offset of this lane's doc row in a stage
+    const int b_off = STAGE_A_BYTES + (wq * 128 + l31) * 64;
+    const int pc0 = ((0 + h) ^ sw) * 16, pc1 = ((2 + h) ^ sw) * 16;
+
+    const int total = (t1 - t0) * p.nks;
+    if (total > 0) issue_stage(p, smem, t0, qb, 0, wave, lane);
+    int g = 0;
+    for (int t = t0; t < t1; ++t) {
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int ks = 0; ks < p.nks; ++ks, ++g) {
+            // stage g has landed (vmcnt(0) before the barrier) and every wave is done
+            // reading the other buffer, which the next stage now overwrites.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (g + 1 < total) {
+                const int nks1 = ks + 1 < p.nks ? ks + 1 : 0;
+                const int nt = ks + 1 < p.nks ? t : t + 1;
+                issue_stage(p, smem + ((g + 1) & 1) * STAGE_BYTES, nt, qb, nks1, wave, lane);
+            }
+            const char* buf = smem + (g & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int pc = s2 ? pc1 : pc0;
+                f32x4 a[2], b[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = *(const f32x4*)(buf + a_off + i * 2048 + pc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = *(const f32x4*)(buf + b_off + j * 2048 + pc);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+            }
+        }
+
+        // ---- epilogue: threshold filter, rare append to the per-query queues ----
+        const int docbase = t * BD + wd * 64 + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ql = wq * 128 + j * 32 + l31;
+            const float tau = taus[ql];
+            float m = acc[0][j][0];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+            if (__any(m > tau)) {
+                uint64_t* qu = myqueues + (size_t)ql * p.cap;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float sc = acc[i][j][r];
+                        const int64_t doc = docbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                        if (sc > tau && doc < p.N) {
+                            const int pos = atomicAdd(&cnts[ql], 1);
+                            if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
+                            else *p.err = 1;
+                        }
+                    }
+            }
+        }
+        // a queue that could overflow on the next tile (<= BD appends) forces a compaction
+        if (__syncthreads_or(cnts[tid] > p.cap - BD)) {
+            // the prefetch of the next tile's first stage is in flight into the bytes the
+            // sort uses: let it land, sort, then issue it again.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int ql = wave; ql < BQ; ql += 4)
+                compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, false, 0, 0);
+            __syncthreads();
+            if (g < total) issue_stage(p, smem + (g & 1) * STAGE_BYTES, t + 1, qb, 0, wave, lane);
+        }
+    }
+    __syncthreads();
+    for (int ql = wave; ql < BQ; ql += 4) {
+        const int64_t qglobal = (int64_t)qb * BQ + ql;
+        if (qglobal < p.nq)
+            compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, true, qglobal, split);
+    }
+}
+
+// every result slot of an empty index: (-FLT_MAX, -1)
+__global__ void __launch_bounds__(256) fill_empty_kernel(float* D, int64_t* I, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { D[i] = -FLT_MAX; I[i] = -1; }
+}
+
+// ---- merge: per query, S lists of (score, id) -> global top-k ---------------------------------
+// One workgroup per query keeps the running best P entries sorted in LDS and folds one list
+// at a time into it (the streaming role of faiss ResultHeap.add_result, reducer.py:16):
+//   load list -> [bitonic sort] -> M[i] = better(R[i], L[P-1-i]) -> bitonic merge.
+// Order: score descending, id ascending; scores <= -FLT_MAX and NaN are empty slots.
+
+__device__ __forceinline__ bool entry_before(uint32_t osa, int64_t ida, uint32_t osb, int64_t idb) {
+    return osa > osb || (osa == osb && ida < idb);
+}
+
+__device__ __forceinline__ void wg_cmpx(uint32_t* os, int64_t* id, int lo, int hi, bool desc) {
+    const uint32_t a = os[lo], b = os[hi];
+    const int64_t ia = id[lo], ib = id[hi];
+    // desc: the better entry goes to lo
+    if (entry_before(b, ib, a, ia) == desc) { os[lo] = b; id[lo] = ib; os[hi] = a; id[hi] = ia; }
+}
+
+__global__ void __launch_bounds__(256)
+merge_topk_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, int S, int64_t nq,
+                  int k_in, int k_out, int P, int lists_sorted, int64_t shard_stride, int64_t query_stride,
+                  float* __restrict__ outD, int64_t* __restrict__ outI) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int64_t* rid = (int64_t*)smem;          // [P]
+    int64_t* lid = rid + P;                 // [P]
+    uint32_t* ros = (uint32_t*)(lid + P);   // [P]
+    uint32_t* los = ros + P;                // [P]
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.x;
+
+    // os == 0 marks an empty slot (every real score orders above 0)
+    for (int i = tid; i < P; i += 256) { ros[i] = 0; rid[i] = INT64_MAX; }
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+        const float* d = D + s * shard_stride + q * query_stride;
+        const int64_t* ids = I + s * shard_stride + q * query_stride;
+        for (int i = tid; i < P; i += 256) {
+            uint32_t o = 0; int64_t id = INT64_MAX;
+            if (i < k_in) {
+                // ResultHeap only admits scores strictly above its neutral value
+                // (-FLT_MAX after the reducer's negation); NaN never compares true.
+                const float sc = d[i];
+                if (sc > -FLT_MAX) { o = f32_ordered(sc); id = ids[i]; }
+            }
+            los[i] = o; lid[i] = id;
+        }
+        __syncthreads();
+        if (!lists_sorted) {
+            for (int size = 2; size <= P; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int i = tid; i < (P >> 1); i += 256) {
+                        const int lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1));
+                        wg_cmpx(los, lid, lo, lo + stride, (lo & size) == 0);
+                    }
+                    __syncthreads();
+                }
+        }
+        // R and L sorted descending: max(R[i], L[P-1-i]) is bitonic and holds the best P
+        for (int i = tid; i < P; i += 256) {
+            const int j = P - 1 - i;
+            if (entry_before(los[j], lid[j], ros[i], rid[i])) { ros[i] = los[j]; rid[i] = lid[j]; }
+        }
+        __syncthreads();
+        for (int stride = P >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (P >> 1); i += 256) {
+                const int lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1));
+                wg_cmpx(ros, rid, lo, lo + stride, true);
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k_out; i += 256) {
+        const bool empty = (i >= P) || ros[i] == 0;
+        outD[q * k_out + i] = empty ? -FLT_MAX : f32_unordered(ros[i]);
+        outI[q * k_out + i] = empty ? -1 : rid[i];
+    }
+}
+
+}  // namespace ipx
