@@ -1,0 +1,168 @@
+"""bench.py — QPS of exact top-100 inner-product search over an 8.8M x 768 fp32 corpus.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one search of all 6980 queries (BASELINE.json: MS MARCO-scale corpus, top-100),
+with the corpus and the queries already resident in HBM. With N > 1 the corpus is row-sharded
+over the ranks (strong scaling: the total corpus is fixed), every rank searches all queries on
+its shard, the (score, id) candidates are all-gathered over RCCL and merged on the GPU.
+
+Rank 0 prints ONE JSON line; see DESIGN.md §Measurement for the roofline arithmetic.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BLOCK_ROWS = 200_000              # synthetic corpus is generated in blocks, seed = 1234 + block
+
+
+def synth_block(torch, dev, block, d):
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + block)
+    return torch.randn((BLOCK_ROWS, d), generator=g, device=dev, dtype=torch.float32)
+
+
+def cpu_baseline(X_sample, Q, k, n_total):
+    """The oracle (faiss-algorithm restatement: blocked sgemm + heap) on this box's host cores,
+    on a bounded sample of the same workload: all queries against the first rows of the same
+    corpus; search time scales linearly in the row count."""
+    import numpy as np
+    from oracle import oracle as O
+    ix = O.FlatIPOracle(Q.shape[1])
+    ix.add(X_sample)
+    t = time.perf_counter()
+    ix.search(Q, k)
+    dt = time.perf_counter() - t
+    scale = n_total / X_sample.shape[0]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or cores
+    return {"value": Q.shape[0] / (dt * scale), "unit": "queries/s", "cores": min(threads, cores), "kind": "port",
+            "sample": f"all {Q.shape[0]} queries x first {X_sample.shape[0]} of {n_total} rows, top-{k}, "
+                      f"{dt:.1f} s measured, scaled x{scale:.1f} in rows; numpy/OpenBLAS sgemm + C heap "
+                      f"(faiss IndexFlatIP restatement; real faiss is not installed on this image)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=8_800_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--queries", type=int, default=6980)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from mural_amd.sharded import ShardedFlatIP, shard_bounds
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n, d, nq, k = args.rows, args.dim, args.queries, args.k
+    lo, hi = shard_bounds(n, world, rank)
+    index = ShardedFlatIP(d, row_lo=lo, device=local_rank)
+    ix = index.engine.index
+    ix.reserve(hi - lo)
+    t_build = time.perf_counter()
+    sample = None
+    for b in range(lo // BLOCK_ROWS, (hi + BLOCK_ROWS - 1) // BLOCK_ROWS):
+        blk = synth_block(torch, dev, b, d)
+        s, e = max(lo, b * BLOCK_ROWS), min(hi, (b + 1) * BLOCK_ROWS)
+        part = blk[s - b * BLOCK_ROWS: e - b * BLOCK_ROWS]
+        index.add_local(part)
+        if rank == 0 and sample is None and not args.no_cpu_baseline:
+            sample = []
+        if rank == 0 and sample is not None and sum(x.shape[0] for x in sample) < args.cpu_sample_rows:
+            sample.append(part[: args.cpu_sample_rows - sum(x.shape[0] for x in sample)].cpu().numpy())
+        torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    Q = torch.randn((nq, d), generator=g, device=dev, dtype=torch.float32)
+
+    ix.set_timing(True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        index.search(Q, k)
+    barrier()
+    scan_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        D, I = index.search(Q, k)
+        # HIP-event time of the scan kernel of this step (events sit on the launch stream;
+        # reading them waits for the kernel, which the step's result needs anyway)
+        scan_ms.append(ix.last_timing()["scan_ms"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ix.check()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    assert int(I.min()) >= 0 and int(I.max()) < n and bool((D[:, :-1] >= D[:, 1:]).all())
+
+    if rank == 0:
+        scan_avg = sum(scan_ms) / len(scan_ms)
+        flops_launch = 2.0 * nq * (hi - lo) * d                      # algorithmic flops of one scan launch
+        achieved = flops_launch / (scan_avg * 1e-3) / 1e12
+        geo = ix.last_geometry()
+        out = {
+            "metric": "QPS exact top-100 IP search, 8.8M×768 corpus @1/8 GPUs; % roofline",
+            "value": nq / (ms_per_step * 1e-3),
+            "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic: torch.randn on device, corpus seed 1234+block, query seed 4321",
+            "config": {"workload": f"{n}x{d} fp32 corpus, {nq} queries, top-{k} (BASELINE.json configs[2] corpus, "
+                                   f"headline depth 100)", "rows": n, "dim": d, "queries": nq, "k": k,
+                       "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
+                       "workgroups": geo["workgroups"], "splits": geo["splits"], "queue_cap": geo["queue_cap"],
+                       "index_build_s": round(t_build, 2)},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "scan_f32_kernel", "kernel_ms": scan_avg,
+                         "flops_per_launch": flops_launch},
+        }
+        if sample is not None and world == 1:
+            Xs = np.concatenate(sample, axis=0)
+            out["cpu_baseline"] = cpu_baseline(Xs, Q.cpu().numpy(), k, n)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

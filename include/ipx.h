@@ -101,6 +101,10 @@ int ipx_search_aspect(ipx_index* idx, const float* aspect_emb, const float* w, i
 int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in, int k_out,
                    float* out_D, int64_t* out_I, int on_device, int device, void* stream);
 
+/* Tuning knobs for tests and benchmarks; results never depend on them.
+ *   "max_splits" : upper bound on the corpus splits per query block (0 = automatic). */
+int ipx_set_param(ipx_index* idx, const char* name, int64_t value);
+
 /* Stream-ordered (on_device) searches return before the kernels finish; this waits for
  * `stream` and reports an invariant violation the kernels flagged (IPX_ERR_STATE), if any.
  * Host-pointer searches do this themselves. */
@@ -121,8 +125,11 @@ int ipx_last_geometry(const ipx_index* idx, int* workgroups, int* splits, int* q
  * like Python's sorted(..., reverse=True) on the score alone) and writes
  *   f"{qid}\t{docid}\t{score}\n"
  * where score is the float32 widened to double and printed with Python's repr(float).
- * qids / docids are arrays of NUL-terminated UTF-8 strings: qids[nq], docids[nq*k]. */
-int ipx_write_ranking(const char* path, const char* const* qids, const char* const* docids,
+ * Ids arrive as numpy '<U' cells: UCS-4 code points, zero padded to the given width
+ * (qids [nq][qid_width], docids [nq*k][docid_width]) and are written as UTF-8; when
+ * docids is NULL, docids_i64 [nq*k] is written in decimal (the reducer's int64 ids). */
+int ipx_write_ranking(const char* path, const uint32_t* qids, int qid_width,
+                      const uint32_t* docids, int docid_width, const int64_t* docids_i64,
                       const float* scores, int64_t nq, int k);
 
 /* Python repr(float(np.float32(x))) into buf (>= 32 bytes). Returns the length. */

@@ -70,6 +70,7 @@ struct ipx_index {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false, ev_merge = false;
     int last_wgs = 0, last_S = 0, last_cap = 0;
+    int max_splits = 0;      // 0 = automatic
     size_t tile_bytes() const { return (size_t)nks * ipx::STAGE_A_BYTES; }
 };
 
@@ -172,6 +173,7 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
         IPX_HIP(hipGetDeviceProperties(&prop, ix->device));
         const int resident = 2 * prop.multiProcessorCount;
         int S = std::max(1, resident / nqb);
+        if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
         S = std::min(S, ntiles);
         const int tps = (ntiles + S - 1) / S;
         S = (ntiles + tps - 1) / tps;
@@ -407,6 +409,16 @@ int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in
     if (!on_device) cleanup();
     if (e != hipSuccess) return fail(IPX_ERR_HIP, std::string("merge: ") + hipGetErrorString(e));
     return 0;
+}
+
+int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
+    if (!ix || !name) return fail(IPX_ERR_ARG, "set_param: null argument");
+    if (!strcmp(name, "max_splits")) {
+        if (value < 0 || value > 65536) return fail(IPX_ERR_ARG, "set_param: max_splits outside [0, 65536]");
+        ix->max_splits = (int)value;
+        return 0;
+    }
+    return fail(IPX_ERR_ARG, std::string("set_param: unknown parameter ") + name);
 }
 
 int ipx_check(ipx_index* ix, void* stream) {

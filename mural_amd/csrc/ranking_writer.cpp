@@ -102,9 +102,36 @@ extern "C" int ipx_format_score(float x, char* buf, size_t buflen) {
     return n;
 }
 
-extern "C" int ipx_write_ranking(const char* path, const char* const* qids, const char* const* docids,
-                                 const float* scores, int64_t nq, int k) {
-    if (!path || nq < 0 || k < 0 || (nq > 0 && (!qids || (k > 0 && (!docids || !scores))))) {
+namespace {
+
+// one id from a numpy '<U' cell (UCS-4 code points, zero padded to `width`) as UTF-8
+inline char* put_ucs4(char* p, const uint32_t* s, int width) {
+    for (int i = 0; i < width && s[i]; ++i) {
+        const uint32_t c = s[i];
+        if (c < 0x80) *p++ = (char)c;
+        else if (c < 0x800) { *p++ = (char)(0xC0 | (c >> 6)); *p++ = (char)(0x80 | (c & 0x3F)); }
+        else if (c < 0x10000) {
+            *p++ = (char)(0xE0 | (c >> 12)); *p++ = (char)(0x80 | ((c >> 6) & 0x3F)); *p++ = (char)(0x80 | (c & 0x3F));
+        } else {
+            *p++ = (char)(0xF0 | (c >> 18)); *p++ = (char)(0x80 | ((c >> 12) & 0x3F));
+            *p++ = (char)(0x80 | ((c >> 6) & 0x3F)); *p++ = (char)(0x80 | (c & 0x3F));
+        }
+    }
+    return p;
+}
+
+inline char* put_i64(char* p, int64_t v) {
+    auto r = std::to_chars(p, p + 24, v);
+    return r.ptr;
+}
+
+}  // namespace
+
+extern "C" int ipx_write_ranking(const char* path, const uint32_t* qids, int qid_width, const uint32_t* docids,
+                                 int docid_width, const int64_t* docids_i64, const float* scores, int64_t nq,
+                                 int k) {
+    if (!path || nq < 0 || k < 0 || qid_width < 0 || docid_width < 0 ||
+        (nq > 0 && (!qids || (k > 0 && ((!docids && !docids_i64) || !scores))))) {
         ipx_set_error_("write_ranking: bad argument");
         return IPX_ERR_ARG;
     }
@@ -113,13 +140,14 @@ extern "C" int ipx_write_ranking(const char* path, const char* const* qids, cons
         ipx_set_error_((std::string("write_ranking: cannot open ") + path).c_str());
         return IPX_ERR_IO;
     }
-    std::vector<char> buf;
-    buf.reserve(1 << 22);
+    const size_t line_max = 4 * (size_t)qid_width + (docids ? 4 * (size_t)docid_width : 24) + 48;
+    const size_t flush_at = 1u << 22;
+    std::vector<char> buf(flush_at + line_max * (size_t)(k > 0 ? k : 1) + 64);
     std::vector<int> order(k);
+    size_t used = 0;
     bool ok = true;
     for (int64_t i = 0; i < nq && ok; ++i) {
         const float* s = scores + i * k;
-        const char* const* ids = docids + i * k;
         std::iota(order.begin(), order.end(), 0);
         // stable, descending by score only (ties keep input order, as Python's sorted does)
         std::stable_sort(order.begin(), order.end(), [s](int a, int b) {
@@ -127,28 +155,24 @@ extern "C" int ipx_write_ranking(const char* path, const char* const* qids, cons
             const float y = std::isnan(s[b]) ? -INFINITY : s[b];
             return x > y;
         });
-        const size_t qlen = strlen(qids[i]);
+        char* p = buf.data() + used;
         for (int j = 0; j < k; ++j) {
             const int h = order[j];
-            const size_t dlen = strlen(ids[h]);
-            const size_t need = qlen + dlen + 48;
-            const size_t at = buf.size();
-            buf.resize(at + need);
-            char* p = buf.data() + at;
-            memcpy(p, qids[i], qlen); p += qlen;
+            p = put_ucs4(p, qids + i * qid_width, qid_width);
             *p++ = '\t';
-            memcpy(p, ids[h], dlen); p += dlen;
+            if (docids) p = put_ucs4(p, docids + ((size_t)i * k + h) * docid_width, docid_width);
+            else p = put_i64(p, docids_i64[(size_t)i * k + h]);
             *p++ = '\t';
             p += py_float_repr((double)s[h], p);
             *p++ = '\n';
-            buf.resize(p - buf.data());
         }
-        if (buf.size() > (1u << 22) - 4096) {
-            ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
-            buf.clear();
+        used = p - buf.data();
+        if (used >= flush_at) {
+            ok = fwrite(buf.data(), 1, used, f) == used;
+            used = 0;
         }
     }
-    if (ok && !buf.empty()) ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    if (ok && used) ok = fwrite(buf.data(), 1, used, f) == used;
     if (fclose(f) != 0) ok = false;
     if (!ok) {
         ipx_set_error_((std::string("write_ranking: write failed on ") + path).c_str());

@@ -1,0 +1,164 @@
+"""Retrieval CLI / driver: `python -m tevatron.faiss_retriever` on the MI355X engine.
+
+Mirrors /root/reference/src/tevatron/faiss_retriever/__main__.py:21-96 — same functions,
+positional arguments, flags, defaults, log lines, input pickles and output bytes. What
+changes is where the work happens: the search runs in libipx.so on the GPU, and the two
+per-hit Python loops of the reference (row id -> doc id strings, and the ranking writer)
+are a vectorised numpy gather and one C call.
+"""
+import ctypes as C
+import glob
+import logging
+import pickle
+from argparse import ArgumentParser
+from itertools import chain
+
+import numpy as np
+from tqdm import tqdm
+
+from .. import _lib
+from .retriever import BaseFaissIPRetriever
+
+logger = logging.getLogger(__name__)
+logging.basicConfig(
+    format="%(asctime)s - %(levelname)s - %(name)s -   %(message)s",
+    datefmt="%m/%d/%Y %H:%M:%S",
+    level=logging.INFO,
+)
+
+
+def _lookup_strings(p_lookup, all_indices):
+    """[[str(p_lookup[x]) for x in row] for row in all_indices] as one '<U' array
+    (__main__.py:27-28), without a Python iteration per hit. Negative row ids index from
+    the end, as they do in the reference (a -1 padding id picks the last document)."""
+    all_indices = np.asarray(all_indices)
+    n = len(p_lookup)
+    flat = all_indices.reshape(-1)
+    if flat.size == 0:
+        return np.array([[str(p_lookup[x]) for x in row] for row in all_indices])
+    if (flat >= n).any() or (flat < -n).any():
+        raise IndexError("list index out of range")
+    if flat.size < n:
+        uniq, inv = np.unique(flat, return_inverse=True)
+        table = np.array([str(p_lookup[int(x)]) for x in uniq])
+        out = table[inv.reshape(-1)].reshape(all_indices.shape)
+    else:
+        table = np.array([str(x) for x in p_lookup])
+        out = table[flat].reshape(all_indices.shape)
+    # np.array(list of str lists) sizes the dtype to the longest string present
+    width = max(int(np.char.str_len(out).max()), 1)
+    return out.astype(f"<U{width}")
+
+
+def search_queries(retriever, q_reps, p_lookup, args):
+    """__main__.py:21-29: chunked search when args.batch_size > 0, one call otherwise; row ids
+    become str(p_lookup[row]) in a '<U' array shaped like the id matrix."""
+    if args.batch_size > 0:
+        all_scores, all_indices = retriever.batch_search(q_reps, args.depth, args.batch_size, args.quiet)
+    else:
+        all_scores, all_indices = retriever.search(q_reps, args.depth)
+    return all_scores, _lookup_strings(p_lookup, all_indices)
+
+
+def _write_ranking_py(corpus_indices, corpus_scores, q_lookup, ranking_save_file):
+    """Generic path for score / id types the C writer does not take: the same ordering
+    (stable sort on the score alone, descending) and the same f-string formatting."""
+    with open(ranking_save_file, 'w') as out:
+        for qid, row_scores, row_ids in zip(q_lookup, corpus_scores, corpus_indices):
+            hits = sorted(zip(row_scores, row_ids), key=lambda hit: hit[0], reverse=True)
+            out.writelines(f'{qid}\t{doc}\t{score}\n' for score, doc in hits)
+
+
+def write_ranking(corpus_indices, corpus_scores, q_lookup, ranking_save_file):
+    """__main__.py:32-38: per query, hits sorted by score descending (stable), one line
+    f'{qid}\\t{idx}\\t{s}\\n' per hit. float32 scores with '<U' or integer ids go through
+    ipx_write_ranking (byte-identical output); anything else takes the Python loop."""
+    scores = np.asarray(corpus_scores)
+    ids = np.asarray(corpus_indices)
+    fast = (scores.dtype == np.float32 and scores.ndim == 2 and ids.shape == scores.shape
+            and ids.dtype.kind in "Uiu" and scores.size > 0)
+    if not fast:
+        return _write_ranking_py(corpus_indices, corpus_scores, q_lookup, ranking_save_file)
+    nq = min(len(q_lookup), scores.shape[0])      # zip() stops at the shortest
+    k = scores.shape[1]
+    qids = np.array([str(q) for q in q_lookup[:nq]]) if nq else np.array([], dtype="<U1")
+    if qids.dtype.kind != "U":
+        return _write_ranking_py(corpus_indices, corpus_scores, q_lookup, ranking_save_file)
+    scores = np.ascontiguousarray(scores[:nq])
+    ids = np.ascontiguousarray(ids[:nq])
+    qw = qids.dtype.itemsize // 4
+    if ids.dtype.kind == "U":
+        dw, dptr, iptr = ids.dtype.itemsize // 4, C.c_void_p(ids.ctypes.data), None
+    else:
+        ids = ids.astype(np.int64, copy=False)
+        dw, dptr, iptr = 0, None, C.c_void_p(ids.ctypes.data)
+    _lib.check(_lib.lib().ipx_write_ranking(
+        str(ranking_save_file).encode(), C.c_void_p(qids.ctypes.data), qw, dptr, dw, iptr,
+        C.c_void_p(scores.ctypes.data), nq, k))
+
+
+def pickle_load(path):
+    """__main__.py:41-48: a pickle holding (reps, lookup) or (reps, lookup, _, _); reps may be
+    an ndarray (f16 / f32) or a list of rows (jax_encode.py:112-114) and comes back as an
+    ndarray. Any other tuple length fails the way the reference does (UnboundLocalError)."""
+    with open(path, 'rb') as f:
+        payload = pickle.load(f)
+    if len(payload) not in (2, 4):
+        raise UnboundLocalError("local variable 'reps' referenced before assignment")
+    return np.array(payload[0]), payload[1]
+
+
+def pickle_save(obj, path):
+    with open(path, 'wb') as f:
+        pickle.dump(obj, f)
+
+
+def _parse_args(argv=None):
+    # the seven flags of __main__.py:57-64, same names, types and defaults
+    parser = ArgumentParser()
+    for flag in ('--query_reps', '--passage_reps', '--save_ranking_to'):
+        parser.add_argument(flag, required=True)
+    parser.add_argument('--batch_size', type=int, default=128)
+    parser.add_argument('--depth', type=int, default=1000)
+    for flag in ('--save_text', '--quiet'):
+        parser.add_argument(flag, action='store_true')
+    return parser.parse_args(argv)
+
+
+def _load_index(pattern):
+    """__main__.py:68-80: glob the shard pickles (file-system order, IndexError when nothing
+    matches), size the index from the first one, add every shard, concatenate the lookups."""
+    index_files = glob.glob(pattern)
+    logger.info(f'Pattern match found {len(index_files)} files; loading them into index.')
+    first = pickle_load(index_files[0])
+    retriever = BaseFaissIPRetriever(first[0])
+    shards = chain([first], map(pickle_load, index_files[1:]))
+    if len(index_files) > 1:
+        shards = tqdm(shards, desc='Loading shards into index', total=len(index_files))
+    look_up = []
+    for p_reps, p_lookup in shards:
+        # float16 shards are widened to float32 on the device (same values as .astype)
+        retriever.add(p_reps if p_reps.dtype == np.float16 else p_reps.astype('float32'))
+        look_up += p_lookup
+    return retriever, look_up
+
+
+def main(argv=None):
+    args = _parse_args(argv)
+    retriever, look_up = _load_index(args.passage_reps)
+
+    q_reps, q_lookup = pickle_load(args.query_reps)
+    q_reps = q_reps.astype('float32')
+
+    logger.info('Index Search Start')
+    all_scores, psg_indices = search_queries(retriever, q_reps, look_up, args)
+    logger.info('Index Search Finished')
+
+    if args.save_text:
+        write_ranking(psg_indices, all_scores, q_lookup, args.save_ranking_to)
+    else:
+        pickle_save((all_scores, psg_indices), args.save_ranking_to)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,193 @@
+"""Host-side mirror of tevatron.faiss_retriever.retriever on the MI355X engine.
+
+Same names, argument meaning and error behaviour as the reference
+(/root/reference/src/tevatron/faiss_retriever/retriever.py:10-42); the arithmetic that the
+reference delegates to faiss.IndexFlatIP runs in libipx.so (hand-written gfx950 kernels,
+C ABI in include/ipx.h). There is no CPU path: without the library or a GPU, calls raise.
+"""
+import ctypes as C
+import logging
+import os
+
+import numpy as np
+from tqdm import tqdm
+
+from .. import _lib
+
+logger = logging.getLogger(__name__)
+
+_NP_DTYPES = {np.dtype("float32"): _lib.IPX_F32, np.dtype("float16"): _lib.IPX_F16}
+
+
+def _is_torch_tensor(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def _torch_stream(x):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+
+
+class FlatIPIndex:
+    """What `BaseFaissIPRetriever.index` is in the reference: a flat inner-product index with
+    `.d`, `.ntotal`, `.add(x)` and `.search(x, k)` (faiss.IndexFlatIP through its numpy
+    wrapper, retriever.py:12,16,19). Rows live on one GPU in the engine's packed layout."""
+
+    def __init__(self, d, device=None):
+        if device is None:
+            device = int(os.environ.get("IPX_DEVICE", "0"))
+        self.d = int(d)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().ipx_create(self.d, self.device, C.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().ipx_destroy(h)
+            except Exception:   # interpreter shutdown
+                pass
+
+    @property
+    def ntotal(self):
+        return int(_lib.lib().ipx_ntotal(self._h))
+
+    @property
+    def is_trained(self):
+        return True
+
+    def reserve(self, n):
+        _lib.check(_lib.lib().ipx_reserve(self._h, int(n)))
+
+    def set_id_base(self, id_base):
+        _lib.check(_lib.lib().ipx_set_id_base(self._h, int(id_base)))
+
+    def add(self, x):
+        """faiss wrapper semantics: x is [n, d]; a dimension mismatch is an AssertionError.
+        float16 rows are widened on the device (the reference widens them on the host,
+        __main__.py:79); torch CUDA tensors (f32 / f16 / bf16) are read in place."""
+        L = _lib.lib()
+        if _is_torch_tensor(x):
+            import torch
+            n, d = x.shape
+            assert d == self.d
+            dt = {torch.float32: _lib.IPX_F32, torch.float16: _lib.IPX_F16, torch.bfloat16: _lib.IPX_BF16}[x.dtype]
+            assert x.is_cuda and x.device.index == self.device
+            x = x.contiguous()
+            _lib.check(L.ipx_add(self._h, C.c_void_p(x.data_ptr()), n, dt, 1, _torch_stream(x)))
+            return
+        n, d = x.shape
+        assert d == self.d
+        if x.dtype not in _NP_DTYPES:
+            x = np.ascontiguousarray(x, dtype="float32")
+        x = np.ascontiguousarray(x)
+        _lib.check(L.ipx_add(self._h, C.c_void_p(x.ctypes.data), n, _NP_DTYPES[x.dtype], 0, None))
+
+    def search(self, x, k):
+        """Returns (D float32 [n, k], I int64 [n, k]) as numpy arrays; rows sorted by score
+        descending, (-FLT_MAX, -1) in slots beyond ntotal — faiss.IndexFlatIP.search."""
+        L = _lib.lib()
+        if _is_torch_tensor(x):
+            return self.search_device(x, k)
+        n, d = x.shape
+        assert d == self.d
+        assert k > 0
+        if k > _lib.IPX_MAX_K:
+            raise ValueError(f"k={k} exceeds the engine limit IPX_MAX_K={_lib.IPX_MAX_K}")
+        x = np.ascontiguousarray(x, dtype="float32")
+        D = np.empty((n, k), dtype=np.float32)
+        I = np.empty((n, k), dtype=np.int64)
+        _lib.check(L.ipx_search(self._h, C.c_void_p(x.ctypes.data), n, k, C.c_void_p(D.ctypes.data),
+                                C.c_void_p(I.ctypes.data), 0, None))
+        return D, I
+
+    def search_device(self, x, k, out=None):
+        """Stream-ordered search on torch CUDA tensors; returns CUDA tensors (D, I)."""
+        import torch
+        L = _lib.lib()
+        n, d = x.shape
+        assert d == self.d
+        assert k > 0
+        x = x.contiguous().float()
+        if out is None:
+            D = torch.empty((n, k), dtype=torch.float32, device=x.device)
+            I = torch.empty((n, k), dtype=torch.int64, device=x.device)
+        else:
+            D, I = out
+        _lib.check(L.ipx_search(self._h, C.c_void_p(x.data_ptr()), n, k, C.c_void_p(D.data_ptr()),
+                                C.c_void_p(I.data_ptr()), 1, _torch_stream(x)))
+        return D, I
+
+    def search_aspect(self, aspect_emb, weights, k, logits=False):
+        """MURAL multi-aspect query (modeling/mul_grain.py:97-110): aspect_emb [n, A, d],
+        weights [n, A] (post-softmax, or logits with logits=True); fused on the device."""
+        L = _lib.lib()
+        aspect_emb = np.ascontiguousarray(aspect_emb, dtype="float32")
+        weights = np.ascontiguousarray(weights, dtype="float32")
+        n, A, d = aspect_emb.shape
+        assert d == self.d
+        assert weights.shape == (n, A)
+        assert k > 0
+        D = np.empty((n, k), dtype=np.float32)
+        I = np.empty((n, k), dtype=np.int64)
+        _lib.check(L.ipx_search_aspect(self._h, C.c_void_p(aspect_emb.ctypes.data), C.c_void_p(weights.ctypes.data),
+                                       A, int(bool(logits)), n, k, C.c_void_p(D.ctypes.data),
+                                       C.c_void_p(I.ctypes.data), 0, None))
+        return D, I
+
+    # bench / profiling helpers
+    def set_param(self, name, value):
+        _lib.check(_lib.lib().ipx_set_param(self._h, name.encode(), int(value)))
+
+    def set_timing(self, on=True):
+        _lib.check(_lib.lib().ipx_set_timing(self._h, int(on)))
+
+    def last_timing(self):
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        _lib.check(_lib.lib().ipx_last_timing(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"pack_ms": a.value, "scan_ms": b.value, "merge_ms": c.value}
+
+    def last_geometry(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(_lib.lib().ipx_last_geometry(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"workgroups": a.value, "splits": b.value, "queue_cap": c.value}
+
+    def check(self, stream=None):
+        _lib.check(_lib.lib().ipx_check(self._h, stream))
+
+
+class BaseFaissIPRetriever:
+    """retriever.py:10-32 — the constructor only takes the dimension from `init_reps`
+    (it does not add the rows); add / search / batch_search forward to the index."""
+
+    def __init__(self, init_reps: np.ndarray):
+        index = FlatIPIndex(init_reps.shape[1])
+        self.index = index
+
+    def add(self, p_reps: np.ndarray):
+        self.index.add(p_reps)
+
+    def search(self, q_reps: np.ndarray, k: int):
+        return self.index.search(q_reps, k)
+
+    def batch_search(self, q_reps: np.ndarray, k: int, batch_size: int, quiet: bool = False):
+        """retriever.py:21-32: search `batch_size` queries at a time (tqdm bar unless quiet)
+        and concatenate; ids equal the unchunked search."""
+        parts = [self.search(q_reps[lo: lo + batch_size], k)
+                 for lo in tqdm(range(0, q_reps.shape[0], batch_size), disable=quiet)]
+        all_scores = np.concatenate([p[0] for p in parts], axis=0)
+        all_indices = np.concatenate([p[1] for p in parts], axis=0)
+        return all_scores, all_indices
+
+
+class FaissRetriever(BaseFaissIPRetriever):
+    """retriever.py:35-42 — index_factory retriever; never referenced by the reference's own
+    code. Only the exact "Flat" factory is served here (anything else is approximate search,
+    out of scope for an exact engine)."""
+
+    def __init__(self, init_reps: np.ndarray, factory_str: str):
+        if factory_str.strip() != "Flat":
+            raise NotImplementedError(
+                f"factory string {factory_str!r}: only the exact 'Flat' inner-product index is implemented")
+        super().__init__(init_reps)

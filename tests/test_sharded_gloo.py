@@ -1,0 +1,86 @@
+"""The N>1 path on CPU: two processes, gloo backend, the same ShardedFlatIP wiring
+(partition -> local top-k with global ids -> all-gather -> merge) that runs over RCCL on the
+GPUs. The per-rank engine is injected: here it is the CPU oracle (tests may use it as the
+checker/stand-in), on the GPU it is the HIP engine (_HipEngine)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine:
+    def __init__(self, d):
+        from oracle import oracle as O
+        self.O, self.d, self.base, self.X = O, d, 0, None
+
+    def set_id_base(self, base):
+        self.base = base
+
+    def add(self, x):
+        x = x.numpy()
+        self.X = x if self.X is None else np.concatenate([self.X, x])
+
+    def search(self, q, k):
+        D, I = self.O.topk_total_order(self.O.scores_mfma_order(q.numpy(), self.X), k, id_base=self.base)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    def merge(self, D, I, k_out):
+        oD, oI = self.O.merge_total_order(D.numpy(), I.numpy(), k_out)
+        return torch.from_numpy(oD), torch.from_numpy(oI)
+
+
+def _worker(rank, world, port, n, d, nq, k, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mural_amd.sharded import ShardedFlatIP, shard_bounds
+        rng = np.random.default_rng(1234)
+        X = rng.standard_normal((n, d), dtype=np.float32)
+        Q = np.random.default_rng(4321).standard_normal((nq, d), dtype=np.float32)
+        lo, hi = shard_bounds(n, world, rank)
+        sh = ShardedFlatIP(d, row_lo=lo, engine=OracleEngine(d))
+        sh.add_local(torch.from_numpy(X[lo:hi]))
+        D, I = sh.search(torch.from_numpy(Q), k)
+        ret[rank] = (D.numpy(), I.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("n,k", [(1001, 10), (333, 200)])
+def test_two_rank_gloo_equals_single_index(n, k):
+    from oracle import oracle as O
+    d, nq, world = 48, 17, 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, d, nq, k, ret), nprocs=world, join=True)
+    X = np.random.default_rng(1234).standard_normal((n, d), dtype=np.float32)
+    Q = np.random.default_rng(4321).standard_normal((nq, d), dtype=np.float32)
+    rD, rI = O.topk_total_order(O.scores_mfma_order(Q, X), k)
+    for rank in range(world):
+        D, I = ret[rank]
+        assert np.array_equal(D, rD) and np.array_equal(I, rI)
+
+
+def test_shard_bounds_cover_rows_exactly():
+    from mural_amd.sharded import shard_bounds
+    for n in (0, 1, 7, 8, 8_800_000, 100_000_001):
+        for w in (1, 2, 4, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
