@@ -102,8 +102,11 @@ int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in
                    float* out_D, int64_t* out_I, int on_device, int device, void* stream);
 
 /* Tuning knobs for tests and benchmarks; results never depend on them.
- *   "max_splits" : upper bound on the corpus splits per query block (0 = automatic). */
+ *   "max_splits" : upper bound on the corpus splits per query block (0 = automatic).
+ *   "trace"      : 1 = every scan workgroup records {start, end (100 MHz ticks), HW_ID,
+ *                  compactions}; read back with ipx_read_trace (profiling aid). */
 int ipx_set_param(ipx_index* idx, const char* name, int64_t value);
+int ipx_read_trace(ipx_index* idx, uint64_t* out, int max_workgroups);
 
 /* Stream-ordered (on_device) searches return before the kernels finish; this waits for
  * `stream` and reports an invariant violation the kernels flagged (IPX_ERR_STATE), if any.

@@ -65,7 +65,8 @@ struct ipx_index {
     int64_t cap_tiles = 0;   // tiles of 128 rows the corpus buffer holds
     int64_t id_base = 0;
     float* Xp = nullptr;     // packed corpus
-    DevBuf Qp, cand, partD, partI, err, stageIn, stageQ, stageW, outD, outI;
+    DevBuf Qp, cand, partD, partI, err, stageIn, stageQ, stageW, outD, outI, trace;
+    bool trace_on = false;
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false, ev_merge = false;
@@ -202,6 +203,11 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
         p.outD = S > 1 ? (float*)ix->partD.p : dD;
         p.outI = S > 1 ? (int64_t*)ix->partI.p : dI;
         p.err = (int*)ix->err.p;
+        p.trace = nullptr;
+        if (ix->trace_on) {
+            if (int rc = ix->trace.ensure((size_t)G * 20 * sizeof(uint64_t))) return rc;   // 4 per workgroup (+16 in stamp builds)
+            p.trace = (uint64_t*)ix->trace.p;
+        }
         p.N = N;
         p.id_base = ix->id_base;
         p.nq = (int)nq;
@@ -288,7 +294,7 @@ int ipx_destroy(ipx_index* ix) {
     (void)hipSetDevice(ix->device);
     if (ix->Xp) (void)hipFree(ix->Xp);
     for (DevBuf* b : {&ix->Qp, &ix->cand, &ix->partD, &ix->partI, &ix->err, &ix->stageIn, &ix->stageQ, &ix->stageW,
-                      &ix->outD, &ix->outI})
+                      &ix->outD, &ix->outI, &ix->trace})
         b->release();
     for (auto& e : ix->ev)
         if (e) (void)hipEventDestroy(e);
@@ -418,7 +424,27 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
         ix->max_splits = (int)value;
         return 0;
     }
+    if (!strcmp(name, "trace")) {
+        ix->trace_on = value != 0;
+        return 0;
+    }
     return fail(IPX_ERR_ARG, std::string("set_param: unknown parameter ") + name);
+}
+
+int ipx_read_trace(ipx_index* ix, uint64_t* out, int max_workgroups) {
+    if (!ix || !out) return fail(IPX_ERR_ARG, "read_trace: null argument");
+    if (!ix->trace_on || !ix->trace.p) return fail(IPX_ERR_STATE, "read_trace: tracing is off (set_param trace 1)");
+    IPX_HIP(hipSetDevice(ix->device));
+    const int n = std::min(max_workgroups, ix->last_wgs);
+    IPX_HIP(hipDeviceSynchronize());
+    IPX_HIP(hipMemcpy(out, ix->trace.p, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+#ifdef IPX_STAMPS
+    // diagnostic build: per-wave cycle sums follow the workgroup records
+    if (max_workgroups >= 5 * ix->last_wgs)
+        IPX_HIP(hipMemcpy(out + (size_t)n * 4, (uint64_t*)ix->trace.p + (size_t)ix->last_wgs * 4,
+                          (size_t)n * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+#endif
+    return 0;
 }
 
 int ipx_check(ipx_index* ix, void* stream) {

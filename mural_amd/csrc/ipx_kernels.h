@@ -57,6 +57,26 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// LDS accesses to the small per-query state (counters, thresholds) while an LDS-DMA stage copy
+// is in flight. hipcc cannot prove that a DS access does not alias the DMA destination, so it
+// puts s_waitcnt vmcnt(0) in front of every one of them — which also waits for the candidate
+// stores issued just before (vmcnt counts stores) and serialises the epilogue on HBM round
+// trips. These never touch the stage buffers, so they are issued from asm with their own
+// lgkmcnt wait (the loads and the wait in ONE statement, outputs early-clobber).
+__device__ __forceinline__ float lds_read_f32_nodma(const float* p) {
+    float v;
+    const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ int lds_atomic_inc_nodma(int* p) {
+    int old;
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int*)p;
+    const int one = 1;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old) : "v"(a), "v"(one) : "memory");
+    return old;
+}
+
 // Blocks b and b+8 share an XCD (and its L2). Give each XCD a contiguous run of logical
 // ids so that the workgroups of one query block sit behind one L2. Bijective for any G.
 __device__ __forceinline__ int xcd_remap(int b, int G) {
@@ -129,6 +149,7 @@ struct ScanParams {
     float* outD;         // [nq][S][k]  sorted partial (or final, when S == 1) scores
     int64_t* outI;       // [nq][S][k]  ids (id_base + row), -1 for empty slots
     int* err;            // set to 1 if a queue would overflow (invariant violation)
+    uint64_t* trace;     // optional [gridDim.x][4]: start, end (100 MHz ticks), HW_ID, compactions
     int64_t N;           // rows in the index
     int64_t id_base;
     int nq, nks, k, cap, S, tps, ntiles;
@@ -219,6 +240,14 @@ scan_f32_kernel(const ScanParams p) {
     const int wd = wave & 1, wq = wave >> 1;
     const int h = lane >> 5, l31 = lane & 31;
 
+    uint64_t t_start = 0;
+    int n_compact = 0;
+#ifdef IPX_STAMPS
+    uint64_t st_vm = 0, st_bar = 0, st_begin = 0, st_epi = 0, st_filter = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_begin) :: "memory");
+#endif
+    if (p.trace) t_start = __builtin_amdgcn_s_memrealtime();
+
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int qb = logical / p.S, split = logical - qb * p.S;
     const int t0 = split * p.tps;
@@ -237,9 +266,29 @@ scan_f32_kernel(const ScanParams p) {
     const int b_off = STAGE_A_BYTES + (wq * 128 + l31) * 64;
     const int pc0 = ((0 + h) ^ sw) * 16, pc1 = ((2 + h) ^ sw) * 16;
 
+    // Software pipeline over the flat stage index g = (tile, K-stage):
+    //   top of stage g : operand set 0 (first 8 features of the stage) is already in registers
+    //   read set 1 (last 8 features) from LDS | 32 MFMAs on set 0        (covers the read)
+    //   vmcnt(0) + barrier: stage g+1 has landed, nobody reads stage g's buffer any more
+    //   issue stage g+2 into stage g's buffer | read set 0 of stage g+1 | 32 MFMAs on set 1
+    // so no MFMA ever waits on an LDS read, and a stage's HBM->LDS copy has one full stage
+    // (4096 MFMA cycles) to land.
     const int total = (t1 - t0) * p.nks;
+    auto stage_tile = [&](int gg) { return t0 + gg / p.nks; };
+    auto stage_ks = [&](int gg) { return gg % p.nks; };
+    f32x4 a0[2], b0[4], a1[2], b1[4];
     if (total > 0) issue_stage(p, smem, t0, qb, 0, wave, lane);
+    if (total > 1) issue_stage(p, smem + STAGE_BYTES, stage_tile(1), qb, stage_ks(1), wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a0[i] = *(const f32x4*)(smem + a_off + i * 2048 + pc0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0[j] = *(const f32x4*)(smem + b_off + j * 2048 + pc0);
+
     int g = 0;
+    // (tile, K-stage) of the next stage to prefetch, g + 2, clamped to the chunk's last tile
+    int pt = stage_tile(2) < t1 ? stage_tile(2) : t1 - 1, pk = stage_ks(2);
     for (int t = t0; t < t1; ++t) {
         f32x16 acc[2][4];
 #pragma unroll
@@ -250,78 +299,157 @@ scan_f32_kernel(const ScanParams p) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         for (int ks = 0; ks < p.nks; ++ks, ++g) {
-            // stage g has landed (vmcnt(0) before the barrier) and every wave is done
-            // reading the other buffer, which the next stage now overwrites.
+            const char* buf = smem + (g & 1) * STAGE_BYTES;
+            const char* nbuf = smem + ((g + 1) & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a1[i] = *(const f32x4*)(buf + a_off + i * 2048 + pc1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b1[j] = *(const f32x4*)(buf + b_off + j * 2048 + pc1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], b0[j][kk], acc[i][j], 0, 0, 0);
+            // issue order: the six LDS reads of set 1 first, then the MFMAs that cover them
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+
+            // keep the 32 MFMAs above the barrier (hipcc would sink them below it and expose
+            // the LDS read latency of set 1)
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef IPX_STAMPS
+            uint64_t s0, s1, s2;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s0) :: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s1) :: "memory");
+            __syncthreads();
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s2) :: "memory");
+            st_vm += s1 - s0;
+            st_bar += s2 - s1;
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (g + 1 < total) {
-                const int nks1 = ks + 1 < p.nks ? ks + 1 : 0;
-                const int nt = ks + 1 < p.nks ? t : t + 1;
-                issue_stage(p, smem + ((g + 1) & 1) * STAGE_BYTES, nt, qb, nks1, wave, lane);
+#endif
+            // No branches from here to the end of the stage, so hipcc can spread the copy
+            // issue and the LDS reads among the 32 MFMAs: past the last stage the prefetch
+            // re-reads the chunk's last tile into a buffer nobody reads again, and the set-0
+            // read returns bytes that are never used.
+            issue_stage(p, smem + (g & 1) * STAGE_BYTES, pt, qb, pk, wave, lane);
+            if (++pk == p.nks) { pk = 0; pt = pt + 1 < t1 ? pt + 1 : pt; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a0[i] = *(const f32x4*)(nbuf + a_off + i * 2048 + pc0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b0[j] = *(const f32x4*)(nbuf + b_off + j * 2048 + pc0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], b1[j][kk], acc[i][j], 0, 0, 0);
+            // issue order below the barrier: MFMAs start at once; the six copy pieces, then the
+            // six LDS reads of the next stage's set 0, go out between pairs of MFMAs
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
             }
-            const char* buf = smem + (g & 1) * STAGE_BYTES;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int pc = s2 ? pc1 : pc0;
-                f32x4 a[2], b[4];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = *(const f32x4*)(buf + a_off + i * 2048 + pc);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = *(const f32x4*)(buf + b_off + j * 2048 + pc);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+            for (int u = 0; u < 6; ++u) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- epilogue: threshold filter, rare append to the per-query queues ----
+#ifdef IPX_STAMPS
+        uint64_t e0;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e0) :: "memory");
+#endif
         const int docbase = t * BD + wd * 64 + 4 * h;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ql = wq * 128 + j * 32 + l31;
-            const float tau = taus[ql];
+            const float tau = lds_read_f32_nodma(&taus[ql]);
             float m = acc[0][j][0];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
             if (__any(m > tau)) {
+                // Rare per element, but some lane of the wave passes on most tiles: branch per
+                // register on the wave-wide vote, so registers nobody passes in cost one compare.
                 uint64_t* qu = myqueues + (size_t)ql * p.cap;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float sc = acc[i][j][r];
-                        const int64_t doc = docbase + i * 32 + (r & 3) + 8 * (r >> 2);
-                        if (sc > tau && doc < p.N) {
-                            const int pos = atomicAdd(&cnts[ql], 1);
-                            if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
-                            else *p.err = 1;
+                        if (__any(sc > tau)) {
+                            const int64_t doc = docbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                            if (sc > tau && doc < p.N) {
+                                const int pos = lds_atomic_inc_nodma(&cnts[ql]);
+                                if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
+                                else *p.err = 1;
+                            }
                         }
                     }
             }
         }
         // a queue that could overflow on the next tile (<= BD appends) forces a compaction
+#ifdef IPX_STAMPS
+        uint64_t em;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(em) :: "memory");
+        st_vm += 0; st_filter += em - e0;
+#endif
         if (__syncthreads_or(cnts[tid] > p.cap - BD)) {
-            // the prefetch of the next tile's first stage is in flight into the bytes the
-            // sort uses: let it land, sort, then issue it again.
+            // The sort scratch aliases both stage buffers, which hold stage g (landed; its
+            // set-0 operands are already in registers) and stage g+1 (in flight): let the
+            // copy land, sort, then fetch both stages again.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            ++n_compact;
             for (int ql = wave; ql < BQ; ql += 4)
                 compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, false, 0, 0);
             __syncthreads();
-            if (g < total) issue_stage(p, smem + (g & 1) * STAGE_BYTES, t + 1, qb, 0, wave, lane);
+            if (g < total) issue_stage(p, smem + (g & 1) * STAGE_BYTES, stage_tile(g), qb, stage_ks(g), wave, lane);
+            if (g + 1 < total)
+                issue_stage(p, smem + ((g + 1) & 1) * STAGE_BYTES, stage_tile(g + 1), qb, stage_ks(g + 1), wave, lane);
+            // set 0 of stage g is already in registers (read before the sort), still valid
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
+#ifdef IPX_STAMPS
+        uint64_t e1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e1) :: "memory");
+        st_epi += e1 - e0;
+#endif
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the clamped tail prefetches write LDS too
     __syncthreads();
     for (int ql = wave; ql < BQ; ql += 4) {
         const int64_t qglobal = (int64_t)qb * BQ + ql;
         if (qglobal < p.nq)
             compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, true, qglobal, split);
+    }
+#ifdef IPX_STAMPS
+    if (p.trace && lane == 0) {   // diagnostic build: per-wave cycle sums
+        uint64_t s_end;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_end) :: "memory");
+        uint64_t* tr = p.trace + (size_t)gridDim.x * 4 + ((size_t)blockIdx.x * 4 + wave) * 4;
+        tr[0] = s_end - st_begin; tr[1] = st_filter; tr[2] = st_bar; tr[3] = st_epi;
+    }
+#endif
+    if (p.trace && tid == 0) {
+        uint64_t* tr = p.trace + (size_t)blockIdx.x * 4;
+        tr[0] = t_start;
+        tr[1] = __builtin_amdgcn_s_memrealtime();
+        tr[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+        tr[3] = (uint64_t)n_compact;
     }
 }
 

@@ -153,6 +153,12 @@ class FlatIPIndex:
         _lib.check(_lib.lib().ipx_last_geometry(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"workgroups": a.value, "splits": b.value, "queue_cap": c.value}
 
+    def read_trace(self):
+        n = self.last_geometry()["workgroups"]
+        out = np.zeros((n, 4), dtype=np.uint64)
+        _lib.check(_lib.lib().ipx_read_trace(self._h, C.c_void_p(out.ctypes.data), n))
+        return out
+
     def check(self, stream=None):
         _lib.check(_lib.lib().ipx_check(self._h, stream))
 

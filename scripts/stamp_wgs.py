@@ -29,6 +29,6 @@ for name, sel in (('paired', ~lone), ('lone', lone)):
     w = wv[sel]
     tot = w[:, :, 0]
     print(name, 'wgs', sel.sum(), 'dur ms %.1f' % (dur[sel].mean() / 1e3), 'cycles/wave %.3e' % tot.mean(),
-          'vmcnt %.1f%%' % (100 * (w[:, :, 1] / tot).mean()), 'barrier %.1f%%' % (100 * (w[:, :, 2] / tot).mean()),
+          'filter %.1f%%' % (100 * (w[:, :, 1] / tot).mean()), 'barrier %.1f%%' % (100 * (w[:, :, 2] / tot).mean()),
           'epilogue %.1f%%' % (100 * (w[:, :, 3] / tot).mean()))
     print('   per wave (mean over wgs): vm', (100 * w[:, :, 1] / tot).mean(0).round(1), 'bar', (100 * w[:, :, 2] / tot).mean(0).round(1))
