@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--queries", type=int, default=6980)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

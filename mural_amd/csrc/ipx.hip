@@ -65,7 +65,7 @@ struct ipx_index {
     int64_t cap_tiles = 0;   // tiles of 128 rows the corpus buffer holds
     int64_t id_base = 0;
     float* Xp = nullptr;     // packed corpus
-    DevBuf Qp, cand, partD, partI, err, stageIn, stageQ, stageW, outD, outI, trace;
+    DevBuf Qp, cand, partD, partI, err, stageIn, stageQ, stageW, outD, outI, trace, pub;
     bool trace_on = false;
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -168,16 +168,16 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
     } else {
         const int nqb = (int)((nq + ipx::BQ - 1) / ipx::BQ);
         const int ntiles = (int)((N + ipx::BD - 1) / ipx::BD);
-        // geometry: all workgroups resident at once (2 per CU), each owns one query block
-        // and one contiguous run of corpus tiles.
+        // geometry: (up to) all workgroups resident at once, 2 per CU; S of them share a query block.
         hipDeviceProp_t prop;
         IPX_HIP(hipGetDeviceProperties(&prop, ix->device));
         const int resident = 2 * prop.multiProcessorCount;
+        // A query block's S workgroups take runs of R corpus tiles from a shared counter.
         int S = std::max(1, resident / nqb);
         if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
-        S = std::min(S, ntiles);
-        const int tps = (ntiles + S - 1) / S;
-        S = (ntiles + tps - 1) / tps;
+        const int R = std::max(4, std::min(64, ntiles / (S * 64)));
+        const int nruns = (ntiles + R - 1) / R;
+        S = std::min(S, nruns);
         const int G = nqb * S;
         const int cap = std::max(512, next_pow2(2 * k));
 
@@ -189,6 +189,11 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
             if (int rc = ix->partI.ensure(nout * S * sizeof(int64_t))) return rc;
         }
         IPX_HIP(hipMemsetAsync(ix->err.p, 0, 256, st));
+        // per search: run counters [nqb] (padded to 256 B) then published thresholds [G][256], all zero
+        const size_t ctr_bytes = ((size_t)nqb * sizeof(uint32_t) + 255) / 256 * 256;
+        const size_t pub_bytes = ctr_bytes + (size_t)G * ipx::BQ * sizeof(uint32_t);
+        if (int rc = ix->pub.ensure(pub_bytes)) return rc;
+        IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
 
         if (ix->timing) IPX_HIP(hipEventRecord(ix->ev[0], st));
         if (int rc = launch_pack(dq, IPX_F32, nq, (int64_t)nqb * ipx::BQ, d, (float*)ix->Qp.p, 0, ipx::BQ, nks, dw, A,
@@ -203,6 +208,10 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
         p.outD = S > 1 ? (float*)ix->partD.p : dD;
         p.outI = S > 1 ? (int64_t*)ix->partI.p : dI;
         p.err = (int*)ix->err.p;
+        p.run_ctr = (uint32_t*)ix->pub.p;
+        p.pub = (uint32_t*)((char*)ix->pub.p + ctr_bytes);
+        p.run_tiles = R;
+        p.r = (k + S - 1) / S;
         p.trace = nullptr;
         if (ix->trace_on) {
             if (int rc = ix->trace.ensure((size_t)G * 20 * sizeof(uint64_t))) return rc;   // 4 per workgroup (+16 in stamp builds)
@@ -215,7 +224,6 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
         p.k = k;
         p.cap = cap;
         p.S = S;
-        p.tps = tps;
         p.ntiles = ntiles;
         const int lds = std::max(2 * ipx::STAGE_BYTES, 4 * cap * 8) + ipx::LDS_STATE_BYTES;
         if (lds > 64 * 1024)
@@ -294,7 +302,7 @@ int ipx_destroy(ipx_index* ix) {
     (void)hipSetDevice(ix->device);
     if (ix->Xp) (void)hipFree(ix->Xp);
     for (DevBuf* b : {&ix->Qp, &ix->cand, &ix->partD, &ix->partI, &ix->err, &ix->stageIn, &ix->stageQ, &ix->stageW,
-                      &ix->outD, &ix->outI, &ix->trace})
+                      &ix->outD, &ix->outI, &ix->trace, &ix->pub})
         b->release();
     for (auto& e : ix->ev)
         if (e) (void)hipEventDestroy(e);

@@ -31,7 +31,7 @@ constexpr int NTHREADS = 256; // 4 waves: 2 (docs) x 2 (queries), each 64 docs x
 constexpr int STAGE_A_BYTES = BD * BK * 4;                 // 8 KiB
 constexpr int STAGE_B_BYTES = BQ * BK * 4;                 // 16 KiB
 constexpr int STAGE_BYTES = STAGE_A_BYTES + STAGE_B_BYTES; // 24 KiB
-constexpr int LDS_STATE_BYTES = 2 * BQ * 4;                // queue counters + thresholds
+constexpr int LDS_STATE_BYTES = 2 * BQ * 4 + 16;           // queue counters + thresholds + 2 flags + run slot
 
 // ---- order-preserving key for (score, row) pairs -------------------------------------------
 // key = ordered(score) << 32 | ~row : larger key = better hit (score desc, row asc).
@@ -77,11 +77,43 @@ __device__ __forceinline__ int lds_atomic_inc_nodma(int* p) {
     return old;
 }
 
-// Blocks b and b+8 share an XCD (and its L2). Give each XCD a contiguous run of logical
-// ids so that the workgroups of one query block sit behind one L2. Bijective for any G.
+__device__ __forceinline__ int lds_read_i32_nodma(const int* p) {
+    int v;
+    const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) int*)p;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_write_i32_nodma(int* p, int v) {
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int*)p;
+    asm volatile("ds_write_b32 %0, %1" : : "v"(a), "v"(v) : "memory");
+}
+
+// Largest float that compares strictly below x (x finite or +inf, not NaN): s > below(x) <=> s >= x.
+__device__ __forceinline__ float f32_below(float x) {
+    const uint32_t u = __float_as_uint(x);
+    if (x == 0.f) return __uint_as_float(0x80000001u);      // both zeros compare equal
+    return __uint_as_float(x > 0.f ? u - 1 : u + 1);
+}
+
+__device__ __forceinline__ bool is_pow4(int n) { return n > 0 && (n & (n - 1)) == 0 && (n & 0x55555555); }
+
+// Workgroup id -> logical id (which query block / split it is). For speed only; any bijection
+// is correct. Observed dispatch: blocks b and b+8 share an XCD (and its L2); on an XCD the
+// first 32 blocks get a CU each and the next 32 become the second workgroup of those CUs, where
+// the earlier-dispatched workgroup wins most MFMA issue slots. So (1) each XCD gets a contiguous
+// run of logical ids: the workgroups of one query block sit behind one L2; (2) inside an XCD,
+// consecutive logical ids alternate first / second workgroup of a CU: every query block gets
+// the same mix of fast and slow workgroups, and the two on a CU read the same query tiles.
 __device__ __forceinline__ int xcd_remap(int b, int G) {
     const int q = G >> 3, r = G & 7, x = b & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    const int n_x = q + (x < r ? 1 : 0);          // blocks on this XCD
+    const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    int j = b >> 3;                                 // dispatch order on this XCD
+    if (n_x > 32 && n_x <= 64) {
+        const int m = n_x - 32;                     // CUs that get a second workgroup
+        j = j >= 32 ? 2 * (j - 32) + 1 : (j < m ? 2 * j : 2 * m + (j - m));
+    }
+    return base + j;
 }
 
 // ---- pack_rows: row-major [n, d] (f32 / f16 / bf16) -> tiled, padded, swizzled fp32 ----------
@@ -150,9 +182,13 @@ struct ScanParams {
     int64_t* outI;       // [nq][S][k]  ids (id_base + row), -1 for empty slots
     int* err;            // set to 1 if a queue would overflow (invariant violation)
     uint64_t* trace;     // optional [gridDim.x][4]: start, end (100 MHz ticks), HW_ID, compactions
+    uint32_t* pub;       // [nqb][S][256] ordered(score of the r-th best hit of that split), 0 = none yet
+    uint32_t* run_ctr;   // [nqb] runs handed out beyond the S pre-assigned ones (zeroed per search)
     int64_t N;           // rows in the index
     int64_t id_base;
-    int nq, nks, k, cap, S, tps, ntiles;
+    int nq, nks, k, cap, S, ntiles;
+    int r;               // ceil(k / S): rank each split publishes (S * r >= k)
+    int run_tiles;       // R: tiles per run of the dynamic corpus split
 };
 
 // bitonic sort, descending, of P (power of two) 64-bit keys in LDS by one wave
@@ -175,9 +211,10 @@ __device__ __forceinline__ void wave_sort_desc(uint64_t* keys, int P, int lane) 
 // threshold, and — on the final call — writes the sorted result row.
 __device__ __forceinline__ void compact_query(const ScanParams& p, uint64_t* scratch, int* cnts,
                                               float* taus, uint64_t* queue, int ql, int lane,
-                                              bool final_pass, int64_t qglobal, int split) {
+                                              bool final_pass, int64_t qglobal, int split, uint32_t* pub_slot) {
     const int n = cnts[ql];
-    if (!final_pass && n <= p.k) return;
+    // nothing to drop and nothing to publish: leave the queue as it is
+    if (!final_pass && n <= p.k && !(pub_slot && n >= p.r)) return;
     int P = 2;
     while (P < n) P <<= 1;
     for (int i = lane; i < P; i += 64) scratch[i] = (i < n) ? queue[i] : 0ull;
@@ -188,7 +225,11 @@ __device__ __forceinline__ void compact_query(const ScanParams& p, uint64_t* scr
         for (int i = lane; i < m; i += 64) queue[i] = scratch[i];
         if (lane == 0) {
             cnts[ql] = m;
-            if (n >= p.k) taus[ql] = f32_unordered((uint32_t)(scratch[p.k - 1] >> 32));
+            // local threshold: the k-th best of this split so far (strict: later rows have larger ids)
+            if (n >= p.k) taus[ql] = fmaxf(taus[ql], f32_unordered((uint32_t)(scratch[p.k - 1] >> 32)));
+            // publish this split's r-th best for the union threshold (see poll_union_threshold)
+            if (pub_slot && n >= p.r)
+                __hip_atomic_store(pub_slot, (uint32_t)(scratch[p.r - 1] >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
         float* oD = p.outD + ((size_t)qglobal * p.S + split) * p.k;
@@ -205,6 +246,24 @@ __device__ __forceinline__ void compact_query(const ScanParams& p, uint64_t* scr
         }
     }
     wave_lds_sync();
+}
+
+// Union threshold. Every split publishes the score of its r-th best hit so far, r = ceil(k/S).
+// Taking the minimum v over the S splits of one query: each split holds >= r rows scoring >= v,
+// so >= S*r >= k rows of the index score >= v and the global k-th best score is >= v. A row
+// scoring below v can therefore never be in the result: thread `tid` raises its query's
+// threshold to just below v (rows scoring exactly v may still win on the id tie-break).
+// Published values only grow, so a stale read is a weaker but still valid bound; the loads are
+// agent-scope (they bypass this CU's L1), no ordering with anything else is needed.
+__device__ __forceinline__ void poll_union_threshold(const ScanParams& p, float* taus, int qb, int tid) {
+    if (p.S <= 1) return;
+    const uint32_t* col = p.pub + (size_t)qb * p.S * BQ + tid;
+    uint32_t v = 0xffffffffu;
+    for (int s2 = 0; s2 < p.S; ++s2) {
+        const uint32_t x = __hip_atomic_load(col + (size_t)s2 * BQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = x < v ? x : v;
+    }
+    if (v != 0) taus[tid] = fmaxf(taus[tid], f32_below(f32_unordered(v)));
 }
 
 __device__ __forceinline__ void issue_stage(const ScanParams& p, char* buf, int64_t tile, int qb,
@@ -225,6 +284,10 @@ __device__ __forceinline__ void issue_stage(const ScanParams& p, char* buf, int6
 #undef IPX_GLDS
 }
 
+// A stage of the scan: K-stage `ks` of corpus tile `t`; ok == false marks "past the end" (the
+// pipeline still issues a copy for it, into a buffer nobody reads, so the loop has no branches).
+struct StageCursor { int t, ks; bool ok; };
+
 __global__ void __launch_bounds__(NTHREADS, 2)
 scan_f32_kernel(const ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -234,6 +297,8 @@ scan_f32_kernel(const ScanParams p) {
     const int stage_region = scratch_bytes > 2 * STAGE_BYTES ? scratch_bytes : 2 * STAGE_BYTES;
     int* cnts = (int*)(smem + stage_region);
     float* taus = (float*)(smem + stage_region + BQ * 4);
+    int* flags = (int*)(smem + stage_region + 2 * BQ * 4);      // [0..1] "a queue is filling up" per tile parity
+    int* runslot = flags + 2;                                    // first tile of the run just claimed
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -243,20 +308,21 @@ scan_f32_kernel(const ScanParams p) {
     uint64_t t_start = 0;
     int n_compact = 0;
 #ifdef IPX_STAMPS
-    uint64_t st_vm = 0, st_bar = 0, st_begin = 0, st_epi = 0, st_filter = 0;
+    uint64_t st_bar = 0, st_begin = 0, st_epi = 0, st_filter = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_begin) :: "memory");
 #endif
     if (p.trace) t_start = __builtin_amdgcn_s_memrealtime();
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int qb = logical / p.S, split = logical - qb * p.S;
-    const int t0 = split * p.tps;
-    const int t1 = (t0 + p.tps < p.ntiles) ? t0 + p.tps : p.ntiles;
 
     // thresholds: -FLT_MAX is faiss's heap neutral (scores must be > it to enter);
     // +inf parks the padding queries of the last block.
     cnts[tid] = 0;
     taus[tid] = ((int64_t)qb * BQ + tid < p.nq) ? -FLT_MAX : INFINITY;
+    if (tid < 2) flags[tid] = 0;
+    uint32_t* mypub = p.S > 1 ? p.pub + ((size_t)qb * p.S + split) * BQ : nullptr;
+    const int fill_limit = p.cap - 2 * BD;      // a set flag is acted on one tile later
 
     uint64_t* myqueues = p.cand + (size_t)blockIdx.x * BQ * p.cap;
     uint64_t* scratch = (uint64_t*)smem + (size_t)wave * p.cap;
@@ -266,19 +332,55 @@ scan_f32_kernel(const ScanParams p) {
     const int b_off = STAGE_A_BYTES + (wq * 128 + l31) * 64;
     const int pc0 = ((0 + h) ^ sw) * 16, pc1 = ((2 + h) ^ sw) * 16;
 
-    // Software pipeline over the flat stage index g = (tile, K-stage):
-    //   top of stage g : operand set 0 (first 8 features of the stage) is already in registers
+    // ---- which tiles this workgroup scans ----------------------------------------------------
+    // The corpus is cut into runs of R tiles. The S workgroups of a query block take runs from a
+    // shared counter (run `split` first, then whatever is next), always in increasing tile order,
+    // so they all finish within one run of each other whatever speed each one gets on its CU.
+    // The next run is claimed when the scan enters the current one, long before it is needed.
+    const int R = p.run_tiles;
+    int adv_end = (split + 1) * R < p.ntiles ? (split + 1) * R : p.ntiles;   // end of the run the prefetch is in
+    int nxt = -1;                                   // first tile of the claimed next run, -1 = none
+    int enter_t = -1;                               // entering this tile means: claim the run after it
+    auto claim_next_run = [&]() {
+        if (tid == 0) {
+            const uint32_t run = (uint32_t)p.S + atomicAdd(p.run_ctr + qb, 1u);
+            *runslot = (int64_t)run * R < p.ntiles ? (int)(run * R) : -1;
+        }
+        __syncthreads();
+        nxt = *runslot;
+        enter_t = -1;
+    };
+    auto advance = [&](StageCursor c) {
+        if (!c.ok) return c;
+        if (++c.ks < p.nks) return c;
+        c.ks = 0;
+        if (c.t + 1 < adv_end) { ++c.t; return c; }
+        if (nxt >= 0) {
+            c.t = nxt;
+            enter_t = nxt;
+            adv_end = nxt + R < p.ntiles ? nxt + R : p.ntiles;
+            nxt = -1;
+            return c;
+        }
+        c.ks = p.nks - 1;      // stay on the last real stage: a harmless re-read
+        c.ok = false;
+        return c;
+    };
+
+    // Software pipeline over the stages c0 (computing), c1, c2 (being copied HBM -> LDS):
+    //   top of stage c0 : operand set 0 (first 8 features of the stage) is already in registers
     //   read set 1 (last 8 features) from LDS | 32 MFMAs on set 0        (covers the read)
-    //   vmcnt(0) + barrier: stage g+1 has landed, nobody reads stage g's buffer any more
-    //   issue stage g+2 into stage g's buffer | read set 0 of stage g+1 | 32 MFMAs on set 1
+    //   vmcnt(0) + barrier: stage c1 has landed, nobody reads stage c0's buffer any more
+    //   issue stage c2 into stage c0's buffer | read set 0 of stage c1 | 32 MFMAs on set 1
     // so no MFMA ever waits on an LDS read, and a stage's HBM->LDS copy has one full stage
     // (4096 MFMA cycles) to land.
-    const int total = (t1 - t0) * p.nks;
-    auto stage_tile = [&](int gg) { return t0 + gg / p.nks; };
-    auto stage_ks = [&](int gg) { return gg % p.nks; };
+    StageCursor c0{split * R, 0, true};
+    claim_next_run();
+    StageCursor c1 = advance(c0);
+    StageCursor c2 = advance(c1);
     f32x4 a0[2], b0[4], a1[2], b1[4];
-    if (total > 0) issue_stage(p, smem, t0, qb, 0, wave, lane);
-    if (total > 1) issue_stage(p, smem + STAGE_BYTES, stage_tile(1), qb, stage_ks(1), wave, lane);
+    issue_stage(p, smem, c0.t, qb, c0.ks, wave, lane);
+    issue_stage(p, smem + STAGE_BYTES, c1.t, qb, c1.ks, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
@@ -286,10 +388,10 @@ scan_f32_kernel(const ScanParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) b0[j] = *(const f32x4*)(smem + b_off + j * 2048 + pc0);
 
-    int g = 0;
-    // (tile, K-stage) of the next stage to prefetch, g + 2, clamped to the chunk's last tile
-    int pt = stage_tile(2) < t1 ? stage_tile(2) : t1 - 1, pk = stage_ks(2);
-    for (int t = t0; t < t1; ++t) {
+    int g = 0, tiles_done = 0;
+    while (c0.ok) {
+        const int t = c0.t;
+        if (t == enter_t) claim_next_run();
         f32x16 acc[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -320,24 +422,19 @@ scan_f32_kernel(const ScanParams p) {
             // the LDS read latency of set 1)
             __builtin_amdgcn_sched_barrier(0);
 #ifdef IPX_STAMPS
-            uint64_t s0, s1, s2;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s0) :: "memory");
+            uint64_t s1, s2;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s1) :: "memory");
             __syncthreads();
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s2) :: "memory");
-            st_vm += s1 - s0;
             st_bar += s2 - s1;
 #else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 #endif
             // No branches from here to the end of the stage, so hipcc can spread the copy
-            // issue and the LDS reads among the 32 MFMAs: past the last stage the prefetch
-            // re-reads the chunk's last tile into a buffer nobody reads again, and the set-0
-            // read returns bytes that are never used.
-            issue_stage(p, smem + (g & 1) * STAGE_BYTES, pt, qb, pk, wave, lane);
-            if (++pk == p.nks) { pk = 0; pt = pt + 1 < t1 ? pt + 1 : pt; }
+            // issue and the LDS reads among the 32 MFMAs.
+            issue_stage(p, smem + (g & 1) * STAGE_BYTES, c2.t, qb, c2.ks, wave, lane);
 #pragma unroll
             for (int i = 0; i < 2; ++i) a0[i] = *(const f32x4*)(nbuf + a_off + i * 2048 + pc0);
 #pragma unroll
@@ -363,14 +460,24 @@ scan_f32_kernel(const ScanParams p) {
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             __builtin_amdgcn_sched_barrier(0);
+            c0 = c1;
+            c1 = c2;
+            c2 = advance(c2);
         }
+        // here c0 / c1 are the first two stages of the next tile of this workgroup (if any),
+        // c0's set-0 operands are in registers, c1's copy is in flight
 
         // ---- epilogue: threshold filter, rare append to the per-query queues ----
 #ifdef IPX_STAMPS
         uint64_t e0;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e0) :: "memory");
 #endif
+        ++tiles_done;
         const int docbase = t * BD + wd * 64 + 4 * h;
+        // flag raised by the PREVIOUS tile's appends: every wave of the workgroup reads the same
+        // value (a tile's barriers lie between those writes and this read; this tile writes the other)
+        bool episode = lds_read_i32_nodma(&flags[(tiles_done + 1) & 1]) != 0;
+        int* myflag = &flags[tiles_done & 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ql = wq * 128 + j * 32 + l31;
@@ -381,7 +488,7 @@ scan_f32_kernel(const ScanParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
             if (__any(m > tau)) {
-                // Rare per element, but some lane of the wave passes on most tiles: branch per
+                // Rare per element, but some lane of the wave passes on many tiles: branch per
                 // register on the wave-wide vote, so registers nobody passes in cost one compare.
                 uint64_t* qu = myqueues + (size_t)ql * p.cap;
 #pragma unroll
@@ -395,33 +502,43 @@ scan_f32_kernel(const ScanParams p) {
                                 const int pos = lds_atomic_inc_nodma(&cnts[ql]);
                                 if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
                                 else *p.err = 1;
+                                if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
                             }
                         }
                     }
             }
         }
-        // a queue that could overflow on the next tile (<= BD appends) forces a compaction
 #ifdef IPX_STAMPS
         uint64_t em;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(em) :: "memory");
-        st_vm += 0; st_filter += em - e0;
+        st_filter += em - e0;
 #endif
-        if (__syncthreads_or(cnts[tid] > p.cap - BD)) {
-            // The sort scratch aliases both stage buffers, which hold stage g (landed; its
-            // set-0 operands are already in registers) and stage g+1 (in flight): let the
+        // Episodes (workgroup-uniform decisions, no per-tile barrier):
+        //  * compaction when a queue is filling up (flag of the previous tile: at most 2*BD more
+        //    appends land before it runs, and fill_limit leaves room for them) and after
+        //    4, 16, 64, ... tiles, so thresholds tighten and get published early in the scan;
+        //  * a threshold poll alone after 8, 32, 128, ... tiles, when the other splits' values
+        //    of the previous round are there.
+        episode = episode || is_pow4(tiles_done);
+        if (episode) {
+            // The sort scratch aliases both stage buffers, which hold stage c0 (landed; its
+            // set-0 operands are already in registers) and stage c1 (in flight): let the
             // copy land, sort, then fetch both stages again.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             ++n_compact;
+            if (tid < 2) flags[tid] = 0;
             for (int ql = wave; ql < BQ; ql += 4)
-                compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, false, 0, 0);
+                compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, false, 0, 0,
+                              mypub ? mypub + ql : nullptr);
             __syncthreads();
-            if (g < total) issue_stage(p, smem + (g & 1) * STAGE_BYTES, stage_tile(g), qb, stage_ks(g), wave, lane);
-            if (g + 1 < total)
-                issue_stage(p, smem + ((g + 1) & 1) * STAGE_BYTES, stage_tile(g + 1), qb, stage_ks(g + 1), wave, lane);
-            // set 0 of stage g is already in registers (read before the sort), still valid
+            poll_union_threshold(p, taus, qb, tid);
+            issue_stage(p, smem + (g & 1) * STAGE_BYTES, c0.t, qb, c0.ks, wave, lane);
+            issue_stage(p, smem + ((g + 1) & 1) * STAGE_BYTES, c1.t, qb, c1.ks, wave, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+        } else if ((tiles_done & 1) == 0 && is_pow4(tiles_done >> 1)) {
+            poll_union_threshold(p, taus, qb, tid);
         }
 #ifdef IPX_STAMPS
         uint64_t e1;
@@ -429,12 +546,12 @@ scan_f32_kernel(const ScanParams p) {
         st_epi += e1 - e0;
 #endif
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the clamped tail prefetches write LDS too
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tail's dummy copies write LDS too
     __syncthreads();
     for (int ql = wave; ql < BQ; ql += 4) {
         const int64_t qglobal = (int64_t)qb * BQ + ql;
         if (qglobal < p.nq)
-            compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, true, qglobal, split);
+            compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, true, qglobal, split, nullptr);
     }
 #ifdef IPX_STAMPS
     if (p.trace && lane == 0) {   // diagnostic build: per-wave cycle sums
@@ -449,7 +566,7 @@ scan_f32_kernel(const ScanParams p) {
         tr[0] = t_start;
         tr[1] = __builtin_amdgcn_s_memrealtime();
         tr[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
-        tr[3] = (uint64_t)n_compact;
+        tr[3] = ((uint64_t)tiles_done << 32) | (uint64_t)n_compact;
     }
 }
 

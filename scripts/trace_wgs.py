@@ -23,7 +23,8 @@ hw = tr[:, 2]
 print('start us: min %.1f max %.1f' % (start.min(), start.max()))
 print('end   us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f' % (end.min(), *np.percentile(end, [10, 50, 90]), end.max()))
 print('dur   us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f' % (dur.min(), *np.percentile(dur, [10, 50, 90]), dur.max()))
-print('compactions: min %d max %d' % (tr[:, 3].min(), tr[:, 3].max()))
+nc, nt = tr[:, 3] & 0xffffffff, tr[:, 3] >> 32
+print('compactions: min %d max %d; tiles per wg: min %d p50 %d max %d' % (nc.min(), nc.max(), nt.min(), np.median(nt), nt.max()))
 # HW_ID fields (gfx9): wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13]
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
 key = se * 32 + sh * 16 + cu
