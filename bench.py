@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: BF16 dense ~2.5 PF
 BLOCK_ROWS = 200_000              # synthetic corpus is generated in blocks, seed = 1234 + block
 
 
@@ -64,6 +65,9 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--storage", choices=["f32", "bf16scan", "bf16"], default="f32",
+                    help="f32: fp32 MFMA scan (headline); bf16scan: bf16 MFMA scan + exact fp32 rescoring "
+                         "(bit-identical results); bf16: bf16 rows only")
     args = ap.parse_args()
 
     import numpy as np
@@ -82,6 +86,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    os.environ["IPX_STORAGE"] = args.storage
     n, d, nq, k = args.rows, args.dim, args.queries, args.k
     lo, hi = shard_bounds(n, world, rank)
     index = ShardedFlatIP(d, row_lo=lo, device=local_rank)
@@ -137,21 +142,26 @@ def main():
         flops_launch = 2.0 * nq * (hi - lo) * d                      # algorithmic flops of one scan launch
         achieved = flops_launch / (scan_avg * 1e-3) / 1e12
         geo = ix.last_geometry()
+        bf = ix.last_bf16_stats()
+        is_bf16 = bf["candidates"] > 0
+        peak = PEAK_BF16_MFMA_TFLOPS if is_bf16 else PEAK_F32_MFMA_TFLOPS
         out = {
             "metric": "QPS exact top-100 IP search, 8.8M×768 corpus @1/8 GPUs; % roofline",
             "value": nq / (ms_per_step * 1e-3),
             "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic: torch.randn on device, corpus seed 1234+block, query seed 4321",
+            "dtype": "bf16 scan + f32 rescoring" if is_bf16 else "f32", "data": "synthetic: torch.randn on device, corpus seed 1234+block, query seed 4321",
             "config": {"workload": f"{n}x{d} fp32 corpus, {nq} queries, top-{k} (BASELINE.json configs[2] corpus, "
                                    f"headline depth 100)", "rows": n, "dim": d, "queries": nq, "k": k,
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
                        "workgroups": geo["workgroups"], "splits": geo["splits"], "queue_cap": geo["queue_cap"],
-                       "index_build_s": round(t_build, 2)},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "scan_f32_kernel", "kernel_ms": scan_avg,
+                       "index_build_s": round(t_build, 2), "storage": args.storage,
+                       "bf16_candidates": bf["candidates"], "fallback_queries": bf["fallback_queries"],
+                       "rescore_ms": round(bf["rescore_ms"], 3), "merge_ms": round(ix.last_timing()["merge_ms"], 3)},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "kernel": "scan_bf16_kernel" if is_bf16 else "scan_f32_kernel", "kernel_ms": scan_avg,
                          "flops_per_launch": flops_launch},
         }
         if sample is not None and world == 1:

@@ -101,7 +101,17 @@ int ipx_search_aspect(ipx_index* idx, const float* aspect_emb, const float* w, i
 int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in, int k_out,
                    float* out_D, int64_t* out_I, int on_device, int device, void* stream);
 
-/* Tuning knobs for tests and benchmarks; results never depend on them.
+/* Index options and tuning knobs. Search RESULTS never depend on any of them, with one
+ * documented exception: storage 2 defines the exact score on the bf16-rounded rows.
+ *   "storage"    : what the index keeps of the added rows; only while the index is empty.
+ *                  0 (default) fp32 rows, fp32 MFMA scan.
+ *                  1 fp32 rows + a bf16 copy: bf16 MFMA scan for candidates, exact fp32
+ *                    rescoring; same scores and ids as storage 0, bit for bit (queries whose
+ *                    candidate list cannot be proven sufficient are repeated on the fp32 scan).
+ *                  2 bf16 rows only (rows given as bf16 are kept exactly, fp32 / f16 rows are
+ *                    rounded to nearest even): bf16 scan, then exact fp32 scores of
+ *                    <fp32 query, stored bf16 row>; half the HBM of storage 0.
+ *   "bf16_candidates" : candidates per query the bf16 scan keeps (0 = automatic: 4k / 2k).
  *   "max_splits" : upper bound on the corpus splits per query block (0 = automatic).
  *   "trace"      : 1 = every scan workgroup records {start, end (100 MHz ticks), HW_ID,
  *                  compactions}; read back with ipx_read_trace (profiling aid). */
@@ -118,6 +128,11 @@ int ipx_check(ipx_index* idx, void* stream);
  * ipx_last_timing synchronises on the recorded events. Any output may be NULL. */
 int ipx_set_timing(ipx_index* idx, int enabled);
 int ipx_last_timing(ipx_index* idx, float* pack_ms, float* scan_ms, float* merge_ms);
+
+/* bf16 scan bookkeeping of the most recent search: time of the rescoring kernel (needs
+ * ipx_set_timing), candidates kept per query (0 = the fp32 scan ran), and how many queries
+ * failed the sufficiency check and were repeated on the fp32 scan. Any output may be NULL. */
+int ipx_last_bf16_stats(ipx_index* idx, float* rescore_ms, int* candidates, int64_t* fallback_queries);
 
 /* Launch geometry chosen by the most recent search: workgroups, corpus splits per
  * query block, candidate-queue capacity. For bench / DESIGN.md bookkeeping. */

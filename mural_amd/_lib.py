@@ -14,6 +14,7 @@ SYMBOLS = [
     "ipx_last_error", "ipx_version", "ipx_device_count", "ipx_create", "ipx_destroy", "ipx_dim",
     "ipx_ntotal", "ipx_reserve", "ipx_set_id_base", "ipx_add", "ipx_search", "ipx_search_aspect",
     "ipx_merge_topk", "ipx_set_param", "ipx_read_trace", "ipx_check", "ipx_set_timing", "ipx_last_timing", "ipx_last_geometry",
+    "ipx_last_bf16_stats",
     "ipx_write_ranking", "ipx_format_score",
 ]
 
@@ -60,6 +61,7 @@ def lib():
     L.ipx_set_timing.argtypes = [vp, i32]
     L.ipx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ipx_last_geometry.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.ipx_last_bf16_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32), C.POINTER(i64)]
     L.ipx_write_ranking.argtypes = [C.c_char_p, vp, i32, vp, i32, vp, vp, i64, i32]
     L.ipx_format_score.argtypes = [C.c_float, C.c_char_p, C.c_size_t]
     _lib = L

@@ -4,7 +4,7 @@
 // and launches the gfx950 kernels. Every entry point cites the reference call it replaces
 // in include/ipx.h. No CPU fallback: without a HIP device every compute call fails with
 // IPX_ERR_HIP.
-#include "ipx_kernels.h"
+#include "ipx_bf16_kernels.h"
 #include "../../include/ipx.h"
 
 #include <algorithm>
@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -64,15 +65,27 @@ struct ipx_index {
     int64_t ntotal = 0;
     int64_t cap_tiles = 0;   // tiles of 128 rows the corpus buffer holds
     int64_t id_base = 0;
-    float* Xp = nullptr;     // packed corpus
+    float* Xp = nullptr;     // packed fp32 corpus (storage 0, 1)
+    // storage: 0 = fp32 rows, fp32 scan; 1 = fp32 rows + a bf16 copy: bf16 scan, fp32 rescoring;
+    //          2 = bf16 rows only (rows given as bf16, or rounded on add): bf16 scan, exact
+    //              rescoring of the stored bf16 values against the fp32 query
+    int storage = 0;
+    int nks_h = 0;           // K-stages of 32 bf16
+    int64_t cap_tiles_h = 0; // tiles of 256 rows the bf16 buffer holds
+    uint16_t* Xh = nullptr;  // packed bf16 corpus (storage 1, 2)
     DevBuf Qp, cand, partD, partI, err, stageIn, stageQ, stageW, outD, outI, trace, pub;
+    DevBuf maxsq, qfused, candD, candI, flags, sel, qsel, selD, selI;
     bool trace_on = false;
     bool timing = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid = false, ev_merge = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false, ev_merge = false, ev_rescore = false;
     int last_wgs = 0, last_S = 0, last_cap = 0;
+    int last_kc = 0;                 // candidates per query of the last bf16 scan (0 = fp32 scan)
+    int64_t last_fallback = 0;       // queries the last search repeated on the fp32 scan
     int max_splits = 0;      // 0 = automatic
+    int force_kc = 0;        // 0 = automatic candidate count
     size_t tile_bytes() const { return (size_t)nks * ipx::STAGE_A_BYTES; }
+    size_t tile_bytes_h() const { return (size_t)nks_h * ipx::HSTAGE_A; }
 };
 
 namespace {
@@ -104,6 +117,43 @@ int grow_corpus(ipx_index* ix, int64_t need_tiles, hipStream_t st) {
     return 0;
 }
 
+int grow_corpus_h(ipx_index* ix, int64_t need_tiles, hipStream_t st) {
+    if (need_tiles <= ix->cap_tiles_h) return 0;
+    int64_t new_tiles = need_tiles;
+    if (ix->cap_tiles_h > 0) new_tiles = std::max(need_tiles, ix->cap_tiles_h + ix->cap_tiles_h / 2);
+    uint16_t* nb = nullptr;
+    hipError_t e = hipMalloc((void**)&nb, (size_t)new_tiles * ix->tile_bytes_h());
+    if (e != hipSuccess && new_tiles > need_tiles) {
+        new_tiles = need_tiles;
+        e = hipMalloc((void**)&nb, (size_t)new_tiles * ix->tile_bytes_h());
+    }
+    if (e != hipSuccess)
+        return fail(IPX_ERR_NOMEM, std::string("hipMalloc(bf16 corpus): ") + hipGetErrorString(e));
+    const size_t old_bytes = (size_t)ix->cap_tiles_h * ix->tile_bytes_h();
+    const size_t new_bytes = (size_t)new_tiles * ix->tile_bytes_h();
+    if (old_bytes) IPX_HIP(hipMemcpyAsync(nb, ix->Xh, old_bytes, hipMemcpyDeviceToDevice, st));
+    IPX_HIP(hipMemsetAsync((char*)nb + old_bytes, 0, new_bytes - old_bytes, st));
+    if (ix->Xh) {
+        IPX_HIP(hipStreamSynchronize(st));
+        (void)hipFree(ix->Xh);
+    }
+    ix->Xh = nb;
+    ix->cap_tiles_h = new_tiles;
+    return 0;
+}
+
+int launch_pack_bf16(const void* src, int dtype, int64_t n, int64_t n_pad, int d, uint16_t* dst, int64_t row0,
+                     int nks_h, hipStream_t st) {
+    const int64_t total = n_pad * nks_h * 4;
+    if (total == 0) return 0;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail(IPX_ERR_ARG, "pack: too many rows in one call");
+    hipLaunchKernelGGL(ipx::pack_rows_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dtype, n, n_pad, d,
+                       dst, row0, nks_h);
+    IPX_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_pack(const void* src, int dtype, int64_t n, int64_t n_pad, int d, float* dst, int64_t row0,
                 int rows_per_tile, int nks, const float* w, int A, int logits, hipStream_t st) {
     const int64_t total = n_pad * nks * 4;
@@ -116,7 +166,313 @@ int launch_pack(const void* src, int dtype, int64_t n, int64_t n_pad, int d, flo
     return 0;
 }
 
+// one slice of rows, already on the device: every copy this index keeps + the norm bound
+int add_device_rows(ipx_index* ix, const void* rows, int dtype, int64_t m, int64_t row0, hipStream_t st) {
+    if (ix->storage != 2)
+        if (int rc = launch_pack(rows, dtype, m, m, ix->d, ix->Xp, row0, ipx::BD, ix->nks, nullptr, 0, 0, st)) return rc;
+    if (ix->storage != 0) {
+        if (int rc = launch_pack_bf16(rows, dtype, m, m, ix->d, ix->Xh, row0, ix->nks_h, st)) return rc;
+        // the margin bound uses |x|_2 of the values the exact score is defined on: the fp32 rows
+        // (storage 1) or the stored bf16 rows (storage 2; rounding can only matter upwards by 2^-8)
+        const int blocks = (int)std::min<int64_t>((m + 3) / 4, 4096);
+        hipLaunchKernelGGL(ipx::row_sumsq_max_kernel, dim3(blocks), dim3(256), 0, st, rows, dtype, m, ix->d,
+                           (uint32_t*)ix->maxsq.p);
+        IPX_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+// room for n rows in every copy this index keeps
+int grow_storage(ipx_index* ix, int64_t n, hipStream_t st) {
+    if (ix->storage != 2)
+        if (int rc = grow_corpus(ix, (n + ipx::BD - 1) / ipx::BD, st)) return rc;
+    if (ix->storage != 0) {
+        if (int rc = grow_corpus_h(ix, (n + ipx::HBD - 1) / ipx::HBD, st)) return rc;
+        if (!ix->maxsq.p) {
+            if (int rc = ix->maxsq.ensure(256)) return rc;
+            IPX_HIP(hipMemsetAsync(ix->maxsq.p, 0, 256, st));
+        }
+    }
+    return 0;
+}
+
 int dtype_size(int dtype) { return dtype == IPX_F32 ? 4 : 2; }
+
+struct Geometry { int nqb, ntiles, S, R, G, cap; };
+
+// fp32 scan of nq row-major fp32 queries already on the device (A > 0: aspect embeddings + weights,
+// fused by the pack kernel): pack -> scan -> merge. Results (device) in dD / dI.
+int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
+                  float* dD, int64_t* dI, hipStream_t st, bool primary) {
+    const bool record = primary && ix->timing;
+    const int d = ix->d, nks = ix->nks;
+    const int64_t N = ix->ntotal;
+    const size_t nout = (size_t)nq * k;
+    const int nqb = (int)((nq + ipx::BQ - 1) / ipx::BQ);
+    const int ntiles = (int)((N + ipx::BD - 1) / ipx::BD);
+    // geometry: (up to) all workgroups resident at once, 2 per CU; S of them share a query block.
+    hipDeviceProp_t prop;
+    IPX_HIP(hipGetDeviceProperties(&prop, ix->device));
+    const int resident = 2 * prop.multiProcessorCount;
+    // A query block's S workgroups take runs of R corpus tiles from a shared counter.
+    int S = std::max(1, resident / nqb);
+    if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
+    const int R = std::max(4, std::min(64, ntiles / (S * 64)));
+    const int nruns = (ntiles + R - 1) / R;
+    S = std::min(S, nruns);
+    const int G = nqb * S;
+    const int cap = std::max(512, next_pow2(2 * k));
+
+    if (int rc = ix->Qp.ensure((size_t)nqb * nks * ipx::STAGE_B_BYTES)) return rc;
+    if (int rc = ix->cand.ensure((size_t)G * ipx::BQ * cap * sizeof(uint64_t))) return rc;
+    if (int rc = ix->err.ensure(256)) return rc;
+    if (S > 1) {
+        if (int rc = ix->partD.ensure(nout * S * sizeof(float))) return rc;
+        if (int rc = ix->partI.ensure(nout * S * sizeof(int64_t))) return rc;
+    }
+    // per search: run counters [nqb] (padded to 256 B) then published thresholds [G][256], all zero
+    const size_t ctr_bytes = ((size_t)nqb * sizeof(uint32_t) + 255) / 256 * 256;
+    const size_t pub_bytes = ctr_bytes + (size_t)G * ipx::BQ * sizeof(uint32_t);
+    if (int rc = ix->pub.ensure(pub_bytes)) return rc;
+    IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
+
+    if (record) IPX_HIP(hipEventRecord(ix->ev[0], st));
+    if (int rc = launch_pack(dq, IPX_F32, nq, (int64_t)nqb * ipx::BQ, d, (float*)ix->Qp.p, 0, ipx::BQ, nks, dw, A,
+                             logits, st))
+        return rc;
+    if (record) IPX_HIP(hipEventRecord(ix->ev[1], st));
+
+    ipx::ScanParams p;
+    p.Xp = ix->Xp;
+    p.Qp = (const float*)ix->Qp.p;
+    p.cand = (uint64_t*)ix->cand.p;
+    p.outD = S > 1 ? (float*)ix->partD.p : dD;
+    p.outI = S > 1 ? (int64_t*)ix->partI.p : dI;
+    p.err = (int*)ix->err.p;
+    p.run_ctr = (uint32_t*)ix->pub.p;
+    p.pub = (uint32_t*)((char*)ix->pub.p + ctr_bytes);
+    p.run_tiles = R;
+    p.r = (k + S - 1) / S;
+    p.trace = nullptr;
+    if (ix->trace_on) {
+        if (int rc = ix->trace.ensure((size_t)G * 20 * sizeof(uint64_t))) return rc;   // 4 per workgroup (+16 in stamp builds)
+        p.trace = (uint64_t*)ix->trace.p;
+    }
+    p.N = N;
+    p.id_base = ix->id_base;
+    p.nq = (int)nq;
+    p.nks = nks;
+    p.k = k;
+    p.cap = cap;
+    p.S = S;
+    p.ntiles = ntiles;
+    const int lds = std::max(2 * ipx::STAGE_BYTES, 4 * cap * 8) + ipx::LDS_STATE_BYTES;
+    if (lds > 64 * 1024)
+        IPX_HIP(hipFuncSetAttribute((const void*)ipx::scan_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(ipx::scan_f32_kernel, dim3(G), dim3(ipx::NTHREADS), lds, st, p);
+    IPX_HIP(hipGetLastError());
+    if (record) IPX_HIP(hipEventRecord(ix->ev[2], st));
+
+    if (S > 1) {
+        const int P = next_pow2(k);
+        const int mlds = P * 24;
+        if (mlds > 64 * 1024)
+            IPX_HIP(hipFuncSetAttribute((const void*)ipx::merge_topk_kernel,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, mlds));
+        // partials are [nq][S][k]: shard stride k, query stride S*k; lists arrive sorted
+        hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st,
+                           (const float*)ix->partD.p, (const int64_t*)ix->partI.p, S, nq, k, k, P, 1,
+                           (int64_t)k, (int64_t)S * k, dD, dI);
+        IPX_HIP(hipGetLastError());
+        if (record) {
+            IPX_HIP(hipEventRecord(ix->ev[3], st));
+            ix->ev_merge = true;
+        }
+    }
+    if (primary) {
+        ix->ev_valid = ix->timing;
+        ix->last_wgs = G;
+        ix->last_S = S;
+        ix->last_cap = cap;
+    }
+    return 0;
+}
+
+// Error coefficient of the margin rule (rescore_kernel): |approx - exact| <= coef * |q| * max|x|.
+//   bf16 rounding (to nearest, unit roundoff u = 2^-9) of q, and of x unless the rows are stored
+//   bf16 and the exact score is defined on them: (1+u)^2 - 1 or u;
+//   fp32 accumulation of the exact chain: (d+1) * 2^-24; of the MFMA chain: 4x that, in case the
+//   matrix core's internal adds are not round-to-nearest; 0.2 % slack for the fp32 norms.
+float margin_coef(int d_pad, bool rows_exact_bf16) {
+    const double u = 1.0 / 512.0;
+    const double round_err = rows_exact_bf16 ? u : (2.0 * u + u * u);
+    const double acc_err = 5.0 * (d_pad + 1) / 16777216.0;
+    return (float)((round_err + acc_err) * 1.002);
+}
+
+// bf16 scan + exact rescoring; queries that fail the margin check go to the fp32 scan (storage 1).
+int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
+                   float* dD, int64_t* dI, hipStream_t st) {
+    const int d = ix->d, nks = ix->nks_h;
+    const int64_t N = ix->ntotal;
+    // candidates per query: 4k (2k when only the query is rounded), within [256, IPX_MAX_K]
+    int kc = ix->force_kc > 0 ? ix->force_kc : std::max(256, (ix->storage == 2 ? 2 : 4) * k);
+    kc = std::min(std::max(kc, k), (int)IPX_MAX_K);
+    const size_t ncand = (size_t)nq * kc;
+
+    const float* qf = dq;
+    if (A > 0) {   // the fused fp32 query is needed row-major for the rescoring
+        if (int rc = ix->qfused.ensure((size_t)nq * d * sizeof(float))) return rc;
+        const int64_t total = nq * (int64_t)d;
+        hipLaunchKernelGGL(ipx::fuse_aspect_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dq, dw, A,
+                           logits, nq, d, (float*)ix->qfused.p);
+        IPX_HIP(hipGetLastError());
+        qf = (const float*)ix->qfused.p;
+    }
+
+    const int nqb = (int)((nq + ipx::BQ - 1) / ipx::BQ);
+    const int ntiles = (int)((N + ipx::HBD - 1) / ipx::HBD);
+    hipDeviceProp_t prop;
+    IPX_HIP(hipGetDeviceProperties(&prop, ix->device));
+    const int resident = prop.multiProcessorCount;          // one 512-thread workgroup per CU
+    int S = std::max(1, resident / nqb);
+    if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
+    const int R = std::max(4, std::min(64, ntiles / (S * 64)));
+    const int nruns = (ntiles + R - 1) / R;
+    S = std::min(S, nruns);
+    const int G = nqb * S;
+    // queue: kc survivors of a compaction + 2 tiles of appends before the next one runs + room to fill
+    const int cap = next_pow2(kc + 2 * ipx::HBD + kc / 2);
+    const int ring = ipx::HNBUF * ipx::HSTAGE;
+    const int nsortwaves = std::max(1, std::min(8, ring / (cap * 8)));
+
+    if (int rc = ix->Qp.ensure((size_t)nqb * nks * ipx::HSTAGE_B)) return rc;
+    if (int rc = ix->cand.ensure((size_t)G * ipx::BQ * cap * sizeof(uint64_t))) return rc;
+    if (int rc = ix->err.ensure(256)) return rc;
+    if (int rc = ix->candD.ensure(ncand * sizeof(float))) return rc;
+    if (int rc = ix->candI.ensure(ncand * sizeof(int64_t))) return rc;
+    if (int rc = ix->flags.ensure((size_t)nq * sizeof(int))) return rc;
+    if (S > 1) {
+        if (int rc = ix->partD.ensure(ncand * S * sizeof(float))) return rc;
+        if (int rc = ix->partI.ensure(ncand * S * sizeof(int64_t))) return rc;
+    }
+    const size_t ctr_bytes = ((size_t)nqb * sizeof(uint32_t) + 255) / 256 * 256;
+    const size_t pub_bytes = ctr_bytes + (size_t)G * ipx::BQ * sizeof(uint32_t);
+    if (int rc = ix->pub.ensure(pub_bytes)) return rc;
+    IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
+
+    if (ix->timing) IPX_HIP(hipEventRecord(ix->ev[0], st));
+    if (int rc = launch_pack_bf16(qf, IPX_F32, nq, (int64_t)nqb * ipx::BQ, d, (uint16_t*)ix->Qp.p, 0, nks, st)) return rc;
+    if (ix->timing) IPX_HIP(hipEventRecord(ix->ev[1], st));
+
+    ipx::ScanParams p;
+    p.Xp = (const float*)ix->Xh;
+    p.Qp = (const float*)ix->Qp.p;
+    p.cand = (uint64_t*)ix->cand.p;
+    p.outD = S > 1 ? (float*)ix->partD.p : (float*)ix->candD.p;
+    p.outI = S > 1 ? (int64_t*)ix->partI.p : (int64_t*)ix->candI.p;
+    p.err = (int*)ix->err.p;
+    p.run_ctr = (uint32_t*)ix->pub.p;
+    p.pub = (uint32_t*)((char*)ix->pub.p + ctr_bytes);
+    p.run_tiles = R;
+    p.r = (kc + S - 1) / S;
+    p.trace = nullptr;
+    p.N = N;
+    p.id_base = ix->id_base;
+    p.nq = (int)nq;
+    p.nks = nks;
+    p.k = kc;
+    p.cap = cap;
+    p.S = S;
+    p.ntiles = ntiles;
+    const int lds = std::max(ring, nsortwaves * cap * 8) + ipx::LDS_STATE_BYTES;
+    IPX_HIP(hipFuncSetAttribute((const void*)ipx::scan_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(ipx::scan_bf16_kernel, dim3(G), dim3(ipx::HTHREADS), lds, st, p, nsortwaves);
+    IPX_HIP(hipGetLastError());
+    if (ix->timing) IPX_HIP(hipEventRecord(ix->ev[2], st));
+
+    if (S > 1) {
+        const int P = next_pow2(kc);
+        const int mlds = P * 24;
+        if (mlds > 64 * 1024)
+            IPX_HIP(hipFuncSetAttribute((const void*)ipx::merge_topk_kernel,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, mlds));
+        hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st,
+                           (const float*)ix->partD.p, (const int64_t*)ix->partI.p, S, nq, kc, kc, P, 1,
+                           (int64_t)kc, (int64_t)S * kc, (float*)ix->candD.p, (int64_t*)ix->candI.p);
+        IPX_HIP(hipGetLastError());
+    }
+    if (ix->timing) {
+        IPX_HIP(hipEventRecord(ix->ev[3], st));
+        ix->ev_merge = true;
+    }
+
+    ipx::RescoreParams rp;
+    rp.candD = (const float*)ix->candD.p;
+    rp.candI = (const int64_t*)ix->candI.p;
+    rp.q = qf;
+    rp.x_is_bf16 = ix->storage == 2;
+    rp.X = rp.x_is_bf16 ? (const void*)ix->Xh : (const void*)ix->Xp;
+    rp.nks = rp.x_is_bf16 ? ix->nks_h : ix->nks;
+    rp.maxsq = (const uint32_t*)ix->maxsq.p;
+    rp.outD = dD;
+    rp.outI = dI;
+    rp.flags = (int*)ix->flags.p;
+    rp.id_base = ix->id_base;
+    rp.coef = margin_coef(ix->nks_h * ipx::HBK, ix->storage == 2);
+    rp.d = d;
+    rp.k = k;
+    rp.kc = kc;
+    rp.P = next_pow2(kc);
+    const int rlds = ((rp.nks * (rp.x_is_bf16 ? 32 : 16) * 4 + 15) & ~15) + rp.P * 8;
+    if (rlds > 64 * 1024)
+        IPX_HIP(hipFuncSetAttribute((const void*)ipx::rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rlds));
+    hipLaunchKernelGGL(ipx::rescore_kernel, dim3((unsigned)nq), dim3(256), rlds, st, rp);
+    IPX_HIP(hipGetLastError());
+    if (ix->timing) {
+        IPX_HIP(hipEventRecord(ix->ev[4], st));
+        ix->ev_rescore = true;
+    }
+    ix->ev_valid = ix->timing;
+    ix->last_wgs = G;
+    ix->last_S = S;
+    ix->last_cap = cap;
+    ix->last_kc = kc;
+
+    // which queries failed the margin check? (the one host round trip of this path)
+    std::vector<int> flags((size_t)nq);
+    IPX_HIP(hipMemcpyAsync(flags.data(), ix->flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st));
+    IPX_HIP(hipStreamSynchronize(st));
+    std::vector<int> sel;
+    for (int64_t i = 0; i < nq; ++i)
+        if (flags[(size_t)i]) sel.push_back((int)i);
+    ix->last_fallback = (int64_t)sel.size();
+    if (sel.empty()) return 0;
+    if (ix->storage != 1)
+        return fail(IPX_ERR_STATE, "search: " + std::to_string(sel.size()) + " of " + std::to_string(nq) +
+                    " queries have more near-ties than the bf16 candidate list holds (kc=" + std::to_string(kc) +
+                    ") and this index keeps no fp32 rows to fall back on; use storage 1 or raise bf16_candidates");
+    int errflag = 0;
+    IPX_HIP(hipMemcpy(&errflag, ix->err.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (errflag) return fail(IPX_ERR_STATE, "search: candidate queue overflow (internal invariant violated)");
+    const int64_t nsel = (int64_t)sel.size();
+    if (int rc = ix->sel.ensure((size_t)nsel * sizeof(int))) return rc;
+    if (int rc = ix->qsel.ensure((size_t)nsel * d * sizeof(float))) return rc;
+    if (int rc = ix->selD.ensure((size_t)nsel * k * sizeof(float))) return rc;
+    if (int rc = ix->selI.ensure((size_t)nsel * k * sizeof(int64_t))) return rc;
+    IPX_HIP(hipMemcpyAsync(ix->sel.p, sel.data(), (size_t)nsel * sizeof(int), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(ipx::gather_rows_kernel, dim3((unsigned)((nsel * d + 255) / 256)), dim3(256), 0, st, qf,
+                       (const int*)ix->sel.p, nsel, d, (float*)ix->qsel.p);
+    IPX_HIP(hipGetLastError());
+    if (int rc = scan_f32_path(ix, (const float*)ix->qsel.p, nullptr, 0, 0, nsel, k, (float*)ix->selD.p,
+                               (int64_t*)ix->selI.p, st, false))
+        return rc;
+    hipLaunchKernelGGL(ipx::scatter_results_kernel, dim3((unsigned)((nsel * k + 255) / 256)), dim3(256), 0, st,
+                       (const float*)ix->selD.p, (const int64_t*)ix->selI.p, (const int*)ix->sel.p, nsel, k, dD, dI);
+    IPX_HIP(hipGetLastError());
+    IPX_HIP(hipStreamSynchronize(st));   // sel (host vector) is read by the copy above
+    return 0;
+}
 
 // Shared body of ipx_search / ipx_search_aspect. q_src is [nq, d] (A == 0) or [nq, A, d].
 int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int logits, int64_t nq, int k,
@@ -130,7 +486,7 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
     if (nq > (int64_t)0x7fffff00) return fail(IPX_ERR_ARG, "search: nq too large for one call");
     IPX_HIP(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;
-    const int d = ix->d, nks = ix->nks;
+    const int d = ix->d;
     const size_t nout = (size_t)nq * k;
 
     // inputs / outputs on the device
@@ -159,6 +515,9 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
         for (auto& e : ix->ev) IPX_HIP(hipEventCreate(&e));
     ix->ev_valid = false;
     ix->ev_merge = false;
+    ix->ev_rescore = false;
+    ix->last_kc = 0;
+    ix->last_fallback = 0;
 
     if (N == 0) {
         // empty index: every slot is (-FLT_MAX, -1), as faiss returns for ntotal == 0
@@ -166,90 +525,14 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
                            (int64_t)nout);
         IPX_HIP(hipGetLastError());
     } else {
-        const int nqb = (int)((nq + ipx::BQ - 1) / ipx::BQ);
-        const int ntiles = (int)((N + ipx::BD - 1) / ipx::BD);
-        // geometry: (up to) all workgroups resident at once, 2 per CU; S of them share a query block.
-        hipDeviceProp_t prop;
-        IPX_HIP(hipGetDeviceProperties(&prop, ix->device));
-        const int resident = 2 * prop.multiProcessorCount;
-        // A query block's S workgroups take runs of R corpus tiles from a shared counter.
-        int S = std::max(1, resident / nqb);
-        if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
-        const int R = std::max(4, std::min(64, ntiles / (S * 64)));
-        const int nruns = (ntiles + R - 1) / R;
-        S = std::min(S, nruns);
-        const int G = nqb * S;
-        const int cap = std::max(512, next_pow2(2 * k));
-
-        if (int rc = ix->Qp.ensure((size_t)nqb * nks * ipx::STAGE_B_BYTES)) return rc;
-        if (int rc = ix->cand.ensure((size_t)G * ipx::BQ * cap * sizeof(uint64_t))) return rc;
         if (int rc = ix->err.ensure(256)) return rc;
-        if (S > 1) {
-            if (int rc = ix->partD.ensure(nout * S * sizeof(float))) return rc;
-            if (int rc = ix->partI.ensure(nout * S * sizeof(int64_t))) return rc;
-        }
         IPX_HIP(hipMemsetAsync(ix->err.p, 0, 256, st));
-        // per search: run counters [nqb] (padded to 256 B) then published thresholds [G][256], all zero
-        const size_t ctr_bytes = ((size_t)nqb * sizeof(uint32_t) + 255) / 256 * 256;
-        const size_t pub_bytes = ctr_bytes + (size_t)G * ipx::BQ * sizeof(uint32_t);
-        if (int rc = ix->pub.ensure(pub_bytes)) return rc;
-        IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
-
-        if (ix->timing) IPX_HIP(hipEventRecord(ix->ev[0], st));
-        if (int rc = launch_pack(dq, IPX_F32, nq, (int64_t)nqb * ipx::BQ, d, (float*)ix->Qp.p, 0, ipx::BQ, nks, dw, A,
-                                 logits, st))
-            return rc;
-        if (ix->timing) IPX_HIP(hipEventRecord(ix->ev[1], st));
-
-        ipx::ScanParams p;
-        p.Xp = ix->Xp;
-        p.Qp = (const float*)ix->Qp.p;
-        p.cand = (uint64_t*)ix->cand.p;
-        p.outD = S > 1 ? (float*)ix->partD.p : dD;
-        p.outI = S > 1 ? (int64_t*)ix->partI.p : dI;
-        p.err = (int*)ix->err.p;
-        p.run_ctr = (uint32_t*)ix->pub.p;
-        p.pub = (uint32_t*)((char*)ix->pub.p + ctr_bytes);
-        p.run_tiles = R;
-        p.r = (k + S - 1) / S;
-        p.trace = nullptr;
-        if (ix->trace_on) {
-            if (int rc = ix->trace.ensure((size_t)G * 20 * sizeof(uint64_t))) return rc;   // 4 per workgroup (+16 in stamp builds)
-            p.trace = (uint64_t*)ix->trace.p;
-        }
-        p.N = N;
-        p.id_base = ix->id_base;
-        p.nq = (int)nq;
-        p.nks = nks;
-        p.k = k;
-        p.cap = cap;
-        p.S = S;
-        p.ntiles = ntiles;
-        const int lds = std::max(2 * ipx::STAGE_BYTES, 4 * cap * 8) + ipx::LDS_STATE_BYTES;
-        if (lds > 64 * 1024)
-            IPX_HIP(hipFuncSetAttribute((const void*)ipx::scan_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(ipx::scan_f32_kernel, dim3(G), dim3(ipx::NTHREADS), lds, st, p);
-        IPX_HIP(hipGetLastError());
-        if (ix->timing) IPX_HIP(hipEventRecord(ix->ev[2], st));
-
-        if (S > 1) {
-            const int P = next_pow2(k);
-            const int mlds = P * 24;
-            if (mlds > 64 * 1024)
-                IPX_HIP(hipFuncSetAttribute((const void*)ipx::merge_topk_kernel,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, mlds));
-            // partials are [nq][S][k]: shard stride k, query stride S*k; lists arrive sorted
-            hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st,
-                               (const float*)ix->partD.p, (const int64_t*)ix->partI.p, S, nq, k, k, P, 1,
-                               (int64_t)k, (int64_t)S * k, dD, dI);
-            IPX_HIP(hipGetLastError());
-            if (ix->timing) IPX_HIP(hipEventRecord(ix->ev[3], st));
-            ix->ev_merge = true;
-        }
-        ix->ev_valid = ix->timing;
-        ix->last_wgs = G;
-        ix->last_S = S;
-        ix->last_cap = cap;
+        // bf16 scan when the index keeps a bf16 copy; with fp32 rows at hand, depths whose
+        // 4k candidates exceed the list limit go straight to the fp32 scan
+        const bool bf16 = ix->storage == 2 || (ix->storage == 1 && (4 * k <= IPX_MAX_K || ix->force_kc > 0));
+        int rc = bf16 ? scan_bf16_path(ix, dq, dw, A, logits, nq, k, dD, dI, st)
+                      : scan_f32_path(ix, dq, dw, A, logits, nq, k, dD, dI, st, true);
+        if (rc) return rc;
     }
 
     if (!on_device) {
@@ -292,6 +575,7 @@ int ipx_create(int d, int device, ipx_index** out) {
     if (!ix) return fail(IPX_ERR_NOMEM, "create: host allocation failed");
     ix->d = d;
     ix->nks = (d + ipx::BK - 1) / ipx::BK;
+    ix->nks_h = (d + ipx::HBK - 1) / ipx::HBK;
     ix->device = device;
     *out = ix;
     return 0;
@@ -301,8 +585,10 @@ int ipx_destroy(ipx_index* ix) {
     if (!ix) return 0;
     (void)hipSetDevice(ix->device);
     if (ix->Xp) (void)hipFree(ix->Xp);
+    if (ix->Xh) (void)hipFree(ix->Xh);
     for (DevBuf* b : {&ix->Qp, &ix->cand, &ix->partD, &ix->partI, &ix->err, &ix->stageIn, &ix->stageQ, &ix->stageW,
-                      &ix->outD, &ix->outI, &ix->trace, &ix->pub})
+                      &ix->outD, &ix->outI, &ix->trace, &ix->pub, &ix->maxsq, &ix->qfused, &ix->candD, &ix->candI,
+                      &ix->flags, &ix->sel, &ix->qsel, &ix->selD, &ix->selI})
         b->release();
     for (auto& e : ix->ev)
         if (e) (void)hipEventDestroy(e);
@@ -316,7 +602,7 @@ int64_t ipx_ntotal(const ipx_index* ix) { return ix ? ix->ntotal : 0; }
 int ipx_reserve(ipx_index* ix, int64_t n) {
     if (!ix || n < 0) return fail(IPX_ERR_ARG, "reserve: bad argument");
     IPX_HIP(hipSetDevice(ix->device));
-    return grow_corpus(ix, (n + ipx::BD - 1) / ipx::BD, nullptr);
+    return grow_storage(ix, n, nullptr);
 }
 
 int ipx_set_id_base(ipx_index* ix, int64_t id_base) {
@@ -334,16 +620,14 @@ int ipx_add(ipx_index* ix, const void* rows, int64_t n, int dtype, int on_device
     if (ix->ntotal + n > (int64_t)0x7fffff00) return fail(IPX_ERR_ARG, "add: more than 2^31 rows in one index");
     IPX_HIP(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = grow_corpus(ix, (ix->ntotal + n + ipx::BD - 1) / ipx::BD, st)) return rc;
+    if (int rc = grow_storage(ix, ix->ntotal + n, st)) return rc;
     const size_t row_bytes = (size_t)ix->d * dtype_size(dtype);
     if (on_device) {
         // pack in slices so one launch's grid stays within 2^31 blocks
         const int64_t slice = std::max<int64_t>(1, (int64_t)(1ull << 30) / ((int64_t)ix->nks * 4));
         for (int64_t r0 = 0; r0 < n; r0 += slice) {
             const int64_t m = std::min(slice, n - r0);
-            if (int rc = launch_pack((const char*)rows + r0 * row_bytes, dtype, m, m, ix->d, ix->Xp, ix->ntotal + r0,
-                                     ipx::BD, ix->nks, nullptr, 0, 0, st))
-                return rc;
+            if (int rc = add_device_rows(ix, (const char*)rows + r0 * row_bytes, dtype, m, ix->ntotal + r0, st)) return rc;
         }
     } else {
         // host rows: stage through a bounded device buffer (256 MiB), one copy per slice
@@ -353,9 +637,7 @@ int ipx_add(ipx_index* ix, const void* rows, int64_t n, int dtype, int on_device
             const int64_t m = std::min(slice, n - r0);
             IPX_HIP(hipMemcpyAsync(ix->stageIn.p, (const char*)rows + r0 * row_bytes, (size_t)m * row_bytes,
                                    hipMemcpyHostToDevice, st));
-            if (int rc = launch_pack(ix->stageIn.p, dtype, m, m, ix->d, ix->Xp, ix->ntotal + r0, ipx::BD, ix->nks,
-                                     nullptr, 0, 0, st))
-                return rc;
+            if (int rc = add_device_rows(ix, ix->stageIn.p, dtype, m, ix->ntotal + r0, st)) return rc;
             IPX_HIP(hipStreamSynchronize(st));   // the staging buffer is reused by the next slice
         }
     }
@@ -432,6 +714,19 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
         ix->max_splits = (int)value;
         return 0;
     }
+    if (!strcmp(name, "storage")) {
+        if (value < 0 || value > 2) return fail(IPX_ERR_ARG, "set_param: storage must be 0 (f32), 1 (f32 + bf16 scan) or 2 (bf16)");
+        if (ix->ntotal > 0 || ix->cap_tiles > 0 || ix->cap_tiles_h > 0)
+            return fail(IPX_ERR_STATE, "set_param: storage can only be chosen while the index is empty and unreserved");
+        if (value != 0 && ix->d > 8192) return fail(IPX_ERR_ARG, "set_param: bf16 storage needs d <= 8192");
+        ix->storage = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "bf16_candidates")) {
+        if (value < 0 || value > IPX_MAX_K) return fail(IPX_ERR_ARG, "set_param: bf16_candidates outside [0, IPX_MAX_K]");
+        ix->force_kc = (int)value;
+        return 0;
+    }
     if (!strcmp(name, "trace")) {
         ix->trace_on = value != 0;
         return 0;
@@ -476,7 +771,7 @@ int ipx_last_timing(ipx_index* ix, float* pack_ms, float* scan_ms, float* merge_
     if (!ix) return fail(IPX_ERR_ARG, "last_timing: null index");
     if (!ix->ev_valid) return fail(IPX_ERR_STATE, "last_timing: no timed search recorded (call ipx_set_timing first)");
     IPX_HIP(hipSetDevice(ix->device));
-    IPX_HIP(hipEventSynchronize(ix->ev[ix->ev_merge ? 3 : 2]));
+    IPX_HIP(hipEventSynchronize(ix->ev[ix->ev_rescore ? 4 : ix->ev_merge ? 3 : 2]));
     float a = 0.f, b = 0.f, c = 0.f;
     IPX_HIP(hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]));
     IPX_HIP(hipEventElapsedTime(&b, ix->ev[1], ix->ev[2]));
@@ -484,6 +779,20 @@ int ipx_last_timing(ipx_index* ix, float* pack_ms, float* scan_ms, float* merge_
     if (pack_ms) *pack_ms = a;
     if (scan_ms) *scan_ms = b;
     if (merge_ms) *merge_ms = c;
+    return 0;
+}
+
+int ipx_last_bf16_stats(ipx_index* ix, float* rescore_ms, int* candidates, int64_t* fallback_queries) {
+    if (!ix) return fail(IPX_ERR_ARG, "last_bf16_stats: null index");
+    float r = 0.f;
+    if (rescore_ms && ix->ev_valid && ix->ev_rescore) {
+        IPX_HIP(hipSetDevice(ix->device));
+        IPX_HIP(hipEventSynchronize(ix->ev[4]));
+        IPX_HIP(hipEventElapsedTime(&r, ix->ev[3], ix->ev[4]));
+    }
+    if (rescore_ms) *rescore_ms = r;
+    if (candidates) *candidates = ix->last_kc;
+    if (fallback_queries) *fallback_queries = ix->last_fallback;
     return 0;
 }
 

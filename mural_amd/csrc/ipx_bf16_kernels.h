@@ -1,0 +1,514 @@
+// ipx_bf16_kernels.h — bf16 scan with exact fp32 rescoring (BASELINE.json configs[3], [4]).
+//
+// The scan kernel finds, per query, the K' > k rows with the largest APPROXIMATE scores
+// (bf16-rounded operands, v_mfma_f32_32x32x16_bf16, fp32 accumulation); rescore_kernel then
+// recomputes those rows' scores exactly — the same ordered fp32 fmaf chain the fp32 scan kernel
+// produces (ipx_kernels.h / oracle orc_scores_mfma_order) — and keeps the best k. The result is
+// PROVABLY the fp32 result whenever the candidate list is long enough, which rescore_kernel
+// checks per query (see margin rule there); queries that fail the check are flagged and the host
+// repeats them on the fp32 scan. So faiss.IndexFlatIP semantics (retriever.py:19) are unchanged.
+//
+// bf16 data layout in HBM (pack_rows_bf16_kernel): tiles of 256 rows; a tile is cut along the
+// feature axis into K-stages of 32 bf16 (64 bytes per row); one stage of one tile is a contiguous
+// [256 rows][4 chunks][8 bf16] block (16 KiB) with the 16-byte chunk c of row r at slot
+// c ^ ((r >> 2) & 3) — byte for byte the geometry of the fp32 layout, so the same linear LDS-DMA
+// copies and conflict-free ds_read_b128 operand reads apply. d is zero-padded to a multiple of 32.
+#pragma once
+#include "ipx_kernels.h"
+
+namespace ipx {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int HBD = 256;          // corpus rows per score tile
+constexpr int HBK = 32;           // bf16 per K-stage
+constexpr int HTHREADS = 512;     // 8 waves: 4 (docs) x 2 (queries), each 64 docs x 128 queries
+constexpr int HNBUF = 4;          // LDS stage ring
+constexpr int HSTAGE_A = HBD * 64;             // 16 KiB
+constexpr int HSTAGE_B = BQ * 64;              // 16 KiB
+constexpr int HSTAGE = HSTAGE_A + HSTAGE_B;    // 32 KiB
+constexpr int HLOADS = HSTAGE / (HTHREADS * 16);   // LDS-DMA pieces per thread per stage (4)
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// MURAL aspect weight a of row r (mul_grain.py:103-105): the value itself, or softmax of logits.
+// Same arithmetic as the fusion in pack_rows_kernel, so both paths see identical query vectors.
+__global__ void __launch_bounds__(256)
+fuse_aspect_kernel(const float* __restrict__ src, const float* __restrict__ w, int A, int logits,
+                   int64_t n, int d, float* __restrict__ dst) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = gid / d;
+    const int e = (int)(gid - r * d);
+    if (r >= n) return;
+    float mx = -INFINITY, den = 0.f;
+    if (logits) {
+        for (int a = 0; a < A; ++a) mx = fmaxf(mx, w[r * A + a]);
+        for (int a = 0; a < A; ++a) den += expf(w[r * A + a] - mx);
+    }
+    float v = 0.f;
+    for (int a = 0; a < A; ++a) {
+        float wa = w[r * A + a];
+        if (logits) wa = expf(wa - mx) / den;
+        v = fmaf(wa, src[(r * A + a) * (int64_t)d + e], v);
+    }
+    dst[gid] = v;
+}
+
+// row-major [n, d] (f32 / f16 / bf16) -> tiled, padded, swizzled bf16 (round to nearest even).
+// One thread per (row, 16-byte chunk of 8 bf16).
+__global__ void __launch_bounds__(256)
+pack_rows_bf16_kernel(const void* __restrict__ src, int dtype, int64_t n, int64_t n_pad, int d,
+                      uint16_t* __restrict__ dst, int64_t row0, int nks) {
+    const int nchunks = nks * 4;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = gid / nchunks;
+    const int c = (int)(gid - r * nchunks);
+    if (r >= n_pad) return;
+    uint16_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < n) {
+        const int k0 = c * 8;
+        const int64_t base = r * (int64_t)d;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (k0 + e < d) {
+                if (dtype == 2) v[e] = ((const uint16_t*)src)[base + k0 + e];
+                else v[e] = f32_to_bf16_rne(load_as_f32(src, dtype, base + k0 + e));
+            }
+    }
+    const int64_t R = row0 + r;
+    const int64_t tile = R / HBD;
+    const int rr = (int)(R - tile * HBD);
+    const int ks = c >> 2, pc = (c & 3) ^ ((rr >> 2) & 3);
+    uint16_t* o = dst + ((tile * nks + ks) * HBD + rr) * 32 + pc * 8;
+    uint4 out;
+    out.x = v[0] | ((uint32_t)v[1] << 16);
+    out.y = v[2] | ((uint32_t)v[3] << 16);
+    out.z = v[4] | ((uint32_t)v[5] << 16);
+    out.w = v[6] | ((uint32_t)v[7] << 16);
+    *(uint4*)o = out;
+}
+
+// max over rows of sum_i x_i^2 (fp32), as float bits in *maxsq (non-negative floats order like
+// unsigned ints; NaN / inf end up on top and make every margin check fail, which is intended).
+// One wave per row, grid-stride.
+__global__ void __launch_bounds__(256)
+row_sumsq_max_kernel(const void* __restrict__ src, int dtype, int64_t n, int d, uint32_t* __restrict__ maxsq) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    float best = 0.f;
+    bool bad = false;
+    for (int64_t r = wave; r < n; r += nwaves) {
+        float s = 0.f;
+        for (int e = lane; e < d; e += 64) {
+            const float x = load_as_f32(src, dtype, r * (int64_t)d + e);
+            s = fmaf(x, x, s);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (!(s <= FLT_MAX)) bad = true;      // NaN or inf
+        best = fmaxf(best, s);
+    }
+    if (lane == 0) atomicMax(maxsq, bad ? 0x7fc00000u : __float_as_uint(best));
+}
+
+// ---- bf16 scan ---------------------------------------------------------------------------------
+#define IPX_DS_READ_B128(dst, addr, off) \
+    asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+
+__device__ __forceinline__ void issue_stage_bf16(const ScanParams& p, char* buf, int64_t tile, int qb,
+                                                 int ks, int wave, int lane) {
+    // A stage and B stage: 16 KiB contiguous each = 2 rounds of 8 waves x 1 KiB
+    const char* ga = (const char*)p.Xp + ((size_t)tile * p.nks + ks) * HSTAGE_A + wave * 1024 + lane * 16;
+    const char* gb = (const char*)p.Qp + ((size_t)qb * p.nks + ks) * HSTAGE_B + wave * 1024 + lane * 16;
+    char* la = buf + wave * 1024;
+    char* lb = buf + HSTAGE_A + wave * 1024;
+#define IPX_GLDS(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g), \
+                                                         (__attribute__((address_space(3))) void*)(l), 16, 0, 0)
+    IPX_GLDS(ga, la);
+    IPX_GLDS(ga + 8192, la + 8192);
+    IPX_GLDS(gb, lb);
+    IPX_GLDS(gb + 8192, lb + 8192);
+#undef IPX_GLDS
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(f32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// Same streaming top-k machinery as scan_f32_kernel (queues, thresholds, compaction episodes,
+// union threshold, dynamic runs); only the tile shape, the stage ring and the MFMA differ.
+// The pipeline keeps HNBUF - 1 stages in flight with counted vmcnt waits; the operand reads are
+// issued from asm (a compiler-visible LDS read after an LDS-DMA copy would get a vmcnt(0)).
+__global__ void __launch_bounds__(HTHREADS)
+scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int scratch_bytes = nsortwaves * p.cap * 8;
+    const int stage_region = scratch_bytes > HNBUF * HSTAGE ? scratch_bytes : HNBUF * HSTAGE;
+    int* cnts = (int*)(smem + stage_region);
+    float* taus = (float*)(smem + stage_region + BQ * 4);
+    int* flags = (int*)(smem + stage_region + 2 * BQ * 4);
+    int* runslot = flags + 2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wd = wave & 3, wq = wave >> 2;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = logical / p.S, split = logical - qb * p.S;
+
+    if (tid < BQ) {
+        cnts[tid] = 0;
+        taus[tid] = ((int64_t)qb * BQ + tid < p.nq) ? -FLT_MAX : INFINITY;
+    }
+    if (tid < 2) flags[tid] = 0;
+    uint32_t* mypub = p.S > 1 ? p.pub + ((size_t)qb * p.S + split) * BQ : nullptr;
+    const int fill_limit = p.cap - 2 * HBD;
+
+    uint64_t* myqueues = p.cand + (size_t)blockIdx.x * BQ * p.cap;
+    uint64_t* scratch = (uint64_t*)smem + (size_t)wave * p.cap;
+
+    const int sw = (lane >> 2) & 3;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t a_off = (wd * 64 + l31) * 64;
+    const uint32_t b_off = HSTAGE_A + (wq * 128 + l31) * 64;
+    const uint32_t pc0 = ((0 + h) ^ sw) * 16, pc1 = ((2 + h) ^ sw) * 16;
+
+    const int R = p.run_tiles;
+    int adv_end = (split + 1) * R < p.ntiles ? (split + 1) * R : p.ntiles;
+    int nxt = -1, enter_t = -1;
+    auto claim_next_run = [&]() {
+        if (tid == 0) {
+            const uint32_t run = (uint32_t)p.S + atomicAdd(p.run_ctr + qb, 1u);
+            *runslot = (int64_t)run * R < p.ntiles ? (int)(run * R) : -1;
+        }
+        __syncthreads();
+        nxt = *runslot;
+        enter_t = -1;
+    };
+    auto advance = [&](StageCursor c) {
+        if (!c.ok) return c;
+        if (++c.ks < p.nks) return c;
+        c.ks = 0;
+        if (c.t + 1 < adv_end) { ++c.t; return c; }
+        if (nxt >= 0) {
+            c.t = nxt;
+            enter_t = nxt;
+            adv_end = nxt + R < p.ntiles ? nxt + R : p.ntiles;
+            nxt = -1;
+            return c;
+        }
+        c.ks = p.nks - 1;
+        c.ok = false;
+        return c;
+    };
+
+    // cur[0] = stage being computed, cur[1..HNBUF-1] = in flight, cur[HNBUF] = next to issue
+    StageCursor cur[HNBUF + 1];
+    cur[0] = StageCursor{split * R, 0, true};
+    claim_next_run();
+#pragma unroll
+    for (int i = 1; i <= HNBUF; ++i) cur[i] = advance(cur[i - 1]);
+#pragma unroll
+    for (int i = 0; i < HNBUF; ++i) issue_stage_bf16(p, smem + i * HSTAGE, cur[i].t, qb, cur[i].ks, wave, lane);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HLOADS * (HNBUF - 1)) : "memory");
+    __syncthreads();
+
+    f32x4 a0[2], b0[4], a1[2], b1[4];
+    {
+        const uint32_t aa = smem_base + a_off + pc0, bb = smem_base + b_off + pc0;
+        IPX_DS_READ_B128(a0[0], aa, 0); IPX_DS_READ_B128(a0[1], aa, 2048);
+        IPX_DS_READ_B128(b0[0], bb, 0); IPX_DS_READ_B128(b0[1], bb, 2048);
+        IPX_DS_READ_B128(b0[2], bb, 4096); IPX_DS_READ_B128(b0[3], bb, 6144);
+    }
+
+    int g = 0, tiles_done = 0;
+    while (cur[0].ok) {
+        const int t = cur[0].t;
+        if (t == enter_t) claim_next_run();
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int ks = 0; ks < p.nks; ++ks, ++g) {
+            const uint32_t buf = smem_base + (g & (HNBUF - 1)) * HSTAGE;
+            const uint32_t nbuf = smem_base + ((g + 1) & (HNBUF - 1)) * HSTAGE;
+            {
+                const uint32_t aa = buf + a_off + pc1, bb = buf + b_off + pc1;
+                IPX_DS_READ_B128(a1[0], aa, 0); IPX_DS_READ_B128(a1[1], aa, 2048);
+                IPX_DS_READ_B128(b1[0], bb, 0); IPX_DS_READ_B128(b1[1], bb, 2048);
+                IPX_DS_READ_B128(b1[2], bb, 4096); IPX_DS_READ_B128(b1[3], bb, 6144);
+            }
+            // set 0 of this stage was read one half-stage ago
+            asm volatile("s_waitcnt lgkmcnt(6)"
+                         : "+v"(a0[0]), "+v"(a0[1]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]) :: "memory");
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0[i]), as_bf16x8(b0[j]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // set 1 is in registers (so nobody reads this stage's buffer any more), the next
+            // stage has landed (HNBUF - 2 younger stages may still be in flight)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(a1[0]), "+v"(a1[1]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]) :: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HLOADS * (HNBUF - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue_stage_bf16(p, smem + (g & (HNBUF - 1)) * HSTAGE, cur[HNBUF].t, qb, cur[HNBUF].ks, wave, lane);
+            {
+                const uint32_t aa = nbuf + a_off + pc0, bb = nbuf + b_off + pc0;
+                IPX_DS_READ_B128(a0[0], aa, 0); IPX_DS_READ_B128(a0[1], aa, 2048);
+                IPX_DS_READ_B128(b0[0], bb, 0); IPX_DS_READ_B128(b0[1], bb, 2048);
+                IPX_DS_READ_B128(b0[2], bb, 4096); IPX_DS_READ_B128(b0[3], bb, 6144);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[i]), as_bf16x8(b1[j]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < HNBUF; ++i) cur[i] = cur[i + 1];
+            cur[HNBUF] = advance(cur[HNBUF]);
+        }
+
+        // ---- epilogue: threshold filter, rare append to the per-query queues ----
+        ++tiles_done;
+        const int docbase = t * HBD + wd * 64 + 4 * h;
+        bool episode = lds_read_i32_nodma(&flags[(tiles_done + 1) & 1]) != 0;
+        int* myflag = &flags[tiles_done & 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ql = wq * 128 + j * 32 + l31;
+            const float tau = lds_read_f32_nodma(&taus[ql]);
+            float m = acc[0][j][0];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+            if (__any(m > tau)) {
+                uint64_t* qu = myqueues + (size_t)ql * p.cap;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float sc = acc[i][j][r];
+                        if (__any(sc > tau)) {
+                            const int64_t doc = docbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                            if (sc > tau && doc < p.N) {
+                                const int pos = lds_atomic_inc_nodma(&cnts[ql]);
+                                if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
+                                else *p.err = 1;
+                                if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
+                            }
+                        }
+                    }
+            }
+        }
+        episode = episode || is_pow4(tiles_done);
+        if (episode) {
+            // the sort scratch aliases the stage ring: let every copy land, sort, fetch the
+            // HNBUF stages again (cur[0]'s set-0 operands are already in registers)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                         : "+v"(a0[0]), "+v"(a0[1]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]) :: "memory");
+            __syncthreads();
+            if (tid < 2) flags[tid] = 0;
+            if (wave < nsortwaves)
+                for (int ql = wave; ql < BQ; ql += nsortwaves)
+                    compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, false, 0, 0,
+                                  mypub ? mypub + ql : nullptr);
+            __syncthreads();
+            if (tid < BQ) poll_union_threshold(p, taus, qb, tid);
+#pragma unroll
+            for (int i = 0; i < HNBUF; ++i)
+                issue_stage_bf16(p, smem + ((g + i) & (HNBUF - 1)) * HSTAGE, cur[i].t, qb, cur[i].ks, wave, lane);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HLOADS * (HNBUF - 1)) : "memory");
+            __syncthreads();
+        } else if ((tiles_done & 1) == 0 && is_pow4(tiles_done >> 1)) {
+            if (tid < BQ) poll_union_threshold(p, taus, qb, tid);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave < nsortwaves)
+        for (int ql = wave; ql < BQ; ql += nsortwaves) {
+            const int64_t qglobal = (int64_t)qb * BQ + ql;
+            if (qglobal < p.nq)
+                compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, true, qglobal, split, nullptr);
+        }
+}
+
+// ---- rescore: candidates (approximate scores) -> exact fp32 scores -> top-k ---------------------
+// Margin rule. Let e be a bound on |approx - exact| for this query over every row (host supplies
+// coef; e = coef * |q|_2 * max_x |x|_2, a Cauchy-Schwarz bound on the bf16 rounding of both
+// operands plus the fp32 accumulation of both chains). Let a_k be the k-th best approximate
+// score. The k rows with the best approximate scores all have exact scores >= a_k - e, so the
+// exact k-th best score is >= a_k - e, so every row of the exact top-k has an approximate score
+// >= a_k - 2e. If the candidate list (the K' best approximate scores) reaches below a_k - 2e —
+// or holds every admissible row of the index — it contains the exact top-k: flag = 0.
+// Otherwise flag = 1 and the host repeats the query on the fp32 scan.
+struct RescoreParams {
+    const float* candD;      // [nq][kc] approximate scores, descending
+    const int64_t* candI;    // [nq][kc] id_base + row, -1 = empty (at the end)
+    const float* q;          // [nq][d] fp32 queries, row-major
+    const void* X;           // packed corpus: fp32 (tiles of 128) or bf16 (tiles of 256)
+    const uint32_t* maxsq;   // float bits of max_x sum x_i^2
+    float* outD;             // [nq][k]
+    int64_t* outI;           // [nq][k]
+    int* flags;              // [nq]
+    int64_t id_base;
+    float coef;
+    int d, nks, x_is_bf16, k, kc, P;
+};
+
+__device__ __forceinline__ float exact_score_f32rows(const float* X, int nks, int64_t row, const float* q) {
+    const int64_t tile = row / BD;
+    const int rr = (int)(row - tile * BD);
+    const int sw = (rr >> 2) & 3;
+    const float* base = X + ((size_t)tile * nks * BD + rr) * 16;
+    float acc = 0.f;
+    for (int ks = 0; ks < nks; ++ks) {
+        const float* st = base + (size_t)ks * BD * 16;
+        const f32x4 c0 = *(const f32x4*)(st + ((0 ^ sw) << 2)), c1 = *(const f32x4*)(st + ((1 ^ sw) << 2));
+        const f32x4 c2 = *(const f32x4*)(st + ((2 ^ sw) << 2)), c3 = *(const f32x4*)(st + ((3 ^ sw) << 2));
+        const float* qq = q + ks * 16;
+        // MFMA 32x32x2 order inside a group of 8 features: 0,4,1,5,2,6,3,7
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc = fmaf(c0[e], qq[e], acc); acc = fmaf(c1[e], qq[4 + e], acc); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc = fmaf(c2[e], qq[8 + e], acc); acc = fmaf(c3[e], qq[12 + e], acc); }
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float exact_score_bf16rows(const uint16_t* X, int nks, int64_t row, const float* q) {
+    const int64_t tile = row / HBD;
+    const int rr = (int)(row - tile * HBD);
+    const int sw = (rr >> 2) & 3;
+    const uint16_t* base = X + ((size_t)tile * nks * HBD + rr) * 32;
+    float acc = 0.f;
+    for (int ks = 0; ks < nks; ++ks) {
+        const uint16_t* st = base + (size_t)ks * HBD * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint4 v = *(const uint4*)(st + ((c ^ sw) << 3));
+            const float* qq = q + ks * 32 + c * 8;
+            // features 0..7 of the chunk: x = lo(v.x), hi(v.x), lo(v.y), hi(v.y), lo(v.z), ...
+            acc = fmaf(bf16_lo(v.x), qq[0], acc); acc = fmaf(bf16_lo(v.z), qq[4], acc);
+            acc = fmaf(bf16_hi(v.x), qq[1], acc); acc = fmaf(bf16_hi(v.z), qq[5], acc);
+            acc = fmaf(bf16_lo(v.y), qq[2], acc); acc = fmaf(bf16_lo(v.w), qq[6], acc);
+            acc = fmaf(bf16_hi(v.y), qq[3], acc); acc = fmaf(bf16_hi(v.w), qq[7], acc);
+        }
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(256)
+rescore_kernel(const RescoreParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dpad = p.nks * (p.x_is_bf16 ? 32 : 16);
+    float* qs = (float*)smem;                                  // [dpad]
+    uint64_t* keys = (uint64_t*)(smem + (size_t)((dpad * 4 + 15) & ~15));   // [P]
+    __shared__ float red[4];
+    __shared__ int s_m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t qi = blockIdx.x;
+    const float* q = p.q + qi * (int64_t)p.d;
+    float ss = 0.f;
+    for (int e = tid; e < dpad; e += 256) {
+        const float v = e < p.d ? q[e] : 0.f;
+        qs[e] = v;
+        ss = fmaf(v, v, ss);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float qsq = red[0] + red[1] + red[2] + red[3];
+    const float eps = p.coef * sqrtf(qsq) * sqrtf(__uint_as_float(*p.maxsq));
+
+    const float* cD = p.candD + qi * (int64_t)p.kc;
+    const int64_t* cI = p.candI + qi * (int64_t)p.kc;
+    if (tid == 0) {
+        // candidates are sorted: valid ones first. binary search the count, then the margin cut.
+        int lo = 0, hi = p.kc;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cI[mid] >= 0) lo = mid + 1; else hi = mid; }
+        const int nvalid = lo;
+        int m = nvalid, flag = 0;
+        if (nvalid >= p.kc) {                       // the list is full: it may have cut rows off
+            const float thr = cD[p.k - 1] - 2.f * eps;   // kc >= k
+            if (cD[p.kc - 1] < thr) {
+                lo = p.k; hi = p.kc;                // first index with score < thr
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (cD[mid] >= thr) lo = mid + 1; else hi = mid; }
+                m = lo;
+            } else {
+                flag = 1;                           // includes eps = NaN / inf
+            }
+        }
+        s_m = m;
+        p.flags[qi] = flag;
+    }
+    __syncthreads();
+    const int m = s_m;
+    for (int i = tid; i < p.P; i += 256) {
+        uint64_t key = 0;
+        if (i < m) {
+            const int64_t row = cI[i] - p.id_base;
+            const float s = p.x_is_bf16 ? exact_score_bf16rows((const uint16_t*)p.X, p.nks, row, qs)
+                                        : exact_score_f32rows((const float*)p.X, p.nks, row, qs);
+            if (s > -FLT_MAX) key = make_key(s, (uint32_t)row);   // the fp32 scan's admission rule
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (int size = 2; size <= p.P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (p.P >> 1); i += 256) {
+                const int lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const uint64_t x = keys[lo], y = keys[hi];
+                if ((x < y) == desc) { keys[lo] = y; keys[hi] = x; }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < p.k; i += 256) {
+        const uint64_t key = i < p.P ? keys[i] : 0;
+        p.outD[qi * p.k + i] = key ? f32_unordered((uint32_t)(key >> 32)) : -FLT_MAX;
+        p.outI[qi * p.k + i] = key ? p.id_base + (int64_t)(uint32_t)(~(uint32_t)key) : -1;
+    }
+}
+
+// rows sel[i] of src -> row i of dst (queries that go back to the fp32 scan), and the way back
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ sel, int64_t nsel, int d, float* __restrict__ dst) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = gid / d;
+    if (r >= nsel) return;
+    const int e = (int)(gid - r * d);
+    dst[gid] = src[(int64_t)sel[r] * d + e];
+}
+__global__ void __launch_bounds__(256)
+scatter_results_kernel(const float* __restrict__ sD, const int64_t* __restrict__ sI, const int* __restrict__ sel,
+                       int64_t nsel, int k, float* __restrict__ D, int64_t* __restrict__ I) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = gid / k;
+    if (r >= nsel) return;
+    const int e = (int)(gid - r * k);
+    D[(int64_t)sel[r] * k + e] = sD[gid];
+    I[(int64_t)sel[r] * k + e] = sI[gid];
+}
+
+}  // namespace ipx

@@ -33,13 +33,21 @@ class FlatIPIndex:
     `.d`, `.ntotal`, `.add(x)` and `.search(x, k)` (faiss.IndexFlatIP through its numpy
     wrapper, retriever.py:12,16,19). Rows live on one GPU in the engine's packed layout."""
 
-    def __init__(self, d, device=None):
+    #: IPX_STORAGE / storage= values (include/ipx.h, ipx_set_param "storage")
+    STORAGE = {"f32": 0, "bf16scan": 1, "bf16": 2}
+
+    def __init__(self, d, device=None, storage=None):
         if device is None:
             device = int(os.environ.get("IPX_DEVICE", "0"))
+        if storage is None:
+            storage = os.environ.get("IPX_STORAGE", "f32")
         self.d = int(d)
         self.device = int(device)
         self._h = C.c_void_p()
         _lib.check(_lib.lib().ipx_create(self.d, self.device, C.byref(self._h)))
+        if self.STORAGE[storage]:
+            self.set_param("storage", self.STORAGE[storage])
+        self.storage = storage
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -147,6 +155,11 @@ class FlatIPIndex:
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         _lib.check(_lib.lib().ipx_last_timing(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"pack_ms": a.value, "scan_ms": b.value, "merge_ms": c.value}
+
+    def last_bf16_stats(self):
+        a, b, c = C.c_float(), C.c_int(), C.c_int64()
+        _lib.check(_lib.lib().ipx_last_bf16_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"rescore_ms": a.value, "candidates": b.value, "fallback_queries": c.value}
 
     def last_geometry(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
