@@ -39,6 +39,13 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the search path.")
+    # torch ships its own HIP runtime; whichever runtime is loaded first serves the whole process.
+    # Load torch's first, so tensors handed to the library and the library's own calls share it
+    # (loaded the other way round, torch finds no GPU afterwards).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32p, i64p = C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p
     L.ipx_last_error.restype = C.c_char_p

@@ -84,6 +84,7 @@ struct ipx_index {
     int64_t last_fallback = 0;       // queries the last search repeated on the fp32 scan
     int max_splits = 0;      // 0 = automatic
     int force_kc = 0;        // 0 = automatic candidate count
+    bool force_f32_scan = false;   // storage 1: use the fp32 scan although a bf16 copy exists
     size_t tile_bytes() const { return (size_t)nks * ipx::STAGE_A_BYTES; }
     size_t tile_bytes_h() const { return (size_t)nks_h * ipx::HSTAGE_A; }
 };
@@ -310,25 +311,15 @@ float margin_coef(int d_pad, bool rows_exact_bf16) {
     return (float)((round_err + acc_err) * 1.002);
 }
 
-// bf16 scan + exact rescoring; queries that fail the margin check go to the fp32 scan (storage 1).
-int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
-                   float* dD, int64_t* dI, hipStream_t st) {
+// One bf16 pass over nq row-major fp32 queries (device): pack -> bf16 scan keeping kc candidates
+// -> merge -> exact rescoring into dD / dI. Synchronises the stream and returns in `flagged` the
+// queries whose candidate list could not be proven sufficient (their rows of dD / dI are not final).
+int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, float* dD, int64_t* dI, hipStream_t st,
+              bool primary, std::vector<int>& flagged) {
     const int d = ix->d, nks = ix->nks_h;
     const int64_t N = ix->ntotal;
-    // candidates per query: 4k (2k when only the query is rounded), within [256, IPX_MAX_K]
-    int kc = ix->force_kc > 0 ? ix->force_kc : std::max(256, (ix->storage == 2 ? 2 : 4) * k);
-    kc = std::min(std::max(kc, k), (int)IPX_MAX_K);
     const size_t ncand = (size_t)nq * kc;
-
-    const float* qf = dq;
-    if (A > 0) {   // the fused fp32 query is needed row-major for the rescoring
-        if (int rc = ix->qfused.ensure((size_t)nq * d * sizeof(float))) return rc;
-        const int64_t total = nq * (int64_t)d;
-        hipLaunchKernelGGL(ipx::fuse_aspect_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dq, dw, A,
-                           logits, nq, d, (float*)ix->qfused.p);
-        IPX_HIP(hipGetLastError());
-        qf = (const float*)ix->qfused.p;
-    }
+    const bool timing = primary && ix->timing;
 
     const int nqb = (int)((nq + ipx::BQ - 1) / ipx::BQ);
     const int ntiles = (int)((N + ipx::HBD - 1) / ipx::HBD);
@@ -361,9 +352,9 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     if (int rc = ix->pub.ensure(pub_bytes)) return rc;
     IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
 
-    if (ix->timing) IPX_HIP(hipEventRecord(ix->ev[0], st));
+    if (timing) IPX_HIP(hipEventRecord(ix->ev[0], st));
     if (int rc = launch_pack_bf16(qf, IPX_F32, nq, (int64_t)nqb * ipx::BQ, d, (uint16_t*)ix->Qp.p, 0, nks, st)) return rc;
-    if (ix->timing) IPX_HIP(hipEventRecord(ix->ev[1], st));
+    if (timing) IPX_HIP(hipEventRecord(ix->ev[1], st));
 
     ipx::ScanParams p;
     p.Xp = (const float*)ix->Xh;
@@ -389,7 +380,7 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     IPX_HIP(hipFuncSetAttribute((const void*)ipx::scan_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(ipx::scan_bf16_kernel, dim3(G), dim3(ipx::HTHREADS), lds, st, p, nsortwaves);
     IPX_HIP(hipGetLastError());
-    if (ix->timing) IPX_HIP(hipEventRecord(ix->ev[2], st));
+    if (timing) IPX_HIP(hipEventRecord(ix->ev[2], st));
 
     if (S > 1) {
         const int P = next_pow2(kc);
@@ -402,7 +393,7 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
                            (int64_t)kc, (int64_t)S * kc, (float*)ix->candD.p, (int64_t*)ix->candI.p);
         IPX_HIP(hipGetLastError());
     }
-    if (ix->timing) {
+    if (timing) {
         IPX_HIP(hipEventRecord(ix->ev[3], st));
         ix->ev_merge = true;
     }
@@ -429,32 +420,37 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
         IPX_HIP(hipFuncSetAttribute((const void*)ipx::rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rlds));
     hipLaunchKernelGGL(ipx::rescore_kernel, dim3((unsigned)nq), dim3(256), rlds, st, rp);
     IPX_HIP(hipGetLastError());
-    if (ix->timing) {
+    if (timing) {
         IPX_HIP(hipEventRecord(ix->ev[4], st));
         ix->ev_rescore = true;
     }
-    ix->ev_valid = ix->timing;
-    ix->last_wgs = G;
-    ix->last_S = S;
-    ix->last_cap = cap;
-    ix->last_kc = kc;
+    if (primary) {
+        ix->ev_valid = ix->timing;
+        ix->last_wgs = G;
+        ix->last_S = S;
+        ix->last_cap = cap;
+        ix->last_kc = kc;
+    }
 
-    // which queries failed the margin check? (the one host round trip of this path)
+    // which queries failed the margin check? (the one host round trip of a pass)
     std::vector<int> flags((size_t)nq);
-    IPX_HIP(hipMemcpyAsync(flags.data(), ix->flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st));
-    IPX_HIP(hipStreamSynchronize(st));
-    std::vector<int> sel;
-    for (int64_t i = 0; i < nq; ++i)
-        if (flags[(size_t)i]) sel.push_back((int)i);
-    ix->last_fallback = (int64_t)sel.size();
-    if (sel.empty()) return 0;
-    if (ix->storage != 1)
-        return fail(IPX_ERR_STATE, "search: " + std::to_string(sel.size()) + " of " + std::to_string(nq) +
-                    " queries have more near-ties than the bf16 candidate list holds (kc=" + std::to_string(kc) +
-                    ") and this index keeps no fp32 rows to fall back on; use storage 1 or raise bf16_candidates");
     int errflag = 0;
-    IPX_HIP(hipMemcpy(&errflag, ix->err.p, sizeof(int), hipMemcpyDeviceToHost));
+    IPX_HIP(hipMemcpyAsync(flags.data(), ix->flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st));
+    IPX_HIP(hipMemcpyAsync(&errflag, ix->err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    IPX_HIP(hipStreamSynchronize(st));
     if (errflag) return fail(IPX_ERR_STATE, "search: candidate queue overflow (internal invariant violated)");
+    flagged.clear();
+    for (int64_t i = 0; i < nq; ++i)
+        if (flags[(size_t)i]) flagged.push_back((int)i);
+    return 0;
+}
+
+// Rows `sel` of the fp32 queries qf, searched again by `again` (a longer-list bf16 pass or the
+// fp32 scan), results written over rows `sel` of dD / dI.
+template <class F>
+int redo_queries(ipx_index* ix, const float* qf, const std::vector<int>& sel, int k, float* dD, int64_t* dI,
+                 hipStream_t st, F again) {
+    const int d = ix->d;
     const int64_t nsel = (int64_t)sel.size();
     if (int rc = ix->sel.ensure((size_t)nsel * sizeof(int))) return rc;
     if (int rc = ix->qsel.ensure((size_t)nsel * d * sizeof(float))) return rc;
@@ -464,14 +460,52 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     hipLaunchKernelGGL(ipx::gather_rows_kernel, dim3((unsigned)((nsel * d + 255) / 256)), dim3(256), 0, st, qf,
                        (const int*)ix->sel.p, nsel, d, (float*)ix->qsel.p);
     IPX_HIP(hipGetLastError());
-    if (int rc = scan_f32_path(ix, (const float*)ix->qsel.p, nullptr, 0, 0, nsel, k, (float*)ix->selD.p,
-                               (int64_t*)ix->selI.p, st, false))
-        return rc;
+    if (int rc = again((const float*)ix->qsel.p, nsel, (float*)ix->selD.p, (int64_t*)ix->selI.p)) return rc;
     hipLaunchKernelGGL(ipx::scatter_results_kernel, dim3((unsigned)((nsel * k + 255) / 256)), dim3(256), 0, st,
                        (const float*)ix->selD.p, (const int64_t*)ix->selI.p, (const int*)ix->sel.p, nsel, k, dD, dI);
     IPX_HIP(hipGetLastError());
-    IPX_HIP(hipStreamSynchronize(st));   // sel (host vector) is read by the copy above
+    IPX_HIP(hipStreamSynchronize(st));   // `sel` (host memory) is read by the copy above
     return 0;
+}
+
+// bf16 scan + exact rescoring. Queries that fail the margin check are repeated with the longest
+// candidate list, and whatever still fails goes to the fp32 scan (storage 1 keeps fp32 rows).
+int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
+                   float* dD, int64_t* dI, hipStream_t st) {
+    const int d = ix->d;
+    // candidates per query: 4k (2k when only the query is rounded), within [256, IPX_MAX_K]
+    int kc = ix->force_kc > 0 ? ix->force_kc : std::max(256, (ix->storage == 2 ? 2 : 4) * k);
+    kc = std::min(std::max(kc, k), (int)IPX_MAX_K);
+
+    const float* qf = dq;
+    if (A > 0) {   // the fused fp32 query is needed row-major for the rescoring
+        if (int rc = ix->qfused.ensure((size_t)nq * d * sizeof(float))) return rc;
+        const int64_t total = nq * (int64_t)d;
+        hipLaunchKernelGGL(ipx::fuse_aspect_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dq, dw, A,
+                           logits, nq, d, (float*)ix->qfused.p);
+        IPX_HIP(hipGetLastError());
+        qf = (const float*)ix->qfused.p;
+    }
+    std::vector<int> flagged;
+    if (int rc = bf16_pass(ix, qf, nq, k, kc, dD, dI, st, true, flagged)) return rc;
+    ix->last_fallback = (int64_t)flagged.size();
+    if (!flagged.empty() && kc < IPX_MAX_K) {
+        std::vector<int> still;
+        int rc = redo_queries(ix, qf, flagged, k, dD, dI, st, [&](const float* q2, int64_t n2, float* D2, int64_t* I2) {
+            return bf16_pass(ix, q2, n2, k, IPX_MAX_K, D2, I2, st, false, still);
+        });
+        if (rc) return rc;
+        for (int& i : still) i = flagged[(size_t)i];
+        flagged.swap(still);
+    }
+    if (flagged.empty()) return 0;
+    if (ix->storage != 1)
+        return fail(IPX_ERR_STATE, "search: " + std::to_string(flagged.size()) + " of " + std::to_string(nq) +
+                    " queries have more near-ties than the longest bf16 candidate list holds (" +
+                    std::to_string((int)IPX_MAX_K) + ") and this index keeps no fp32 rows to fall back on; use storage 1");
+    return redo_queries(ix, qf, flagged, k, dD, dI, st, [&](const float* q2, int64_t n2, float* D2, int64_t* I2) {
+        return scan_f32_path(ix, q2, nullptr, 0, 0, n2, k, D2, I2, st, false);
+    });
 }
 
 // Shared body of ipx_search / ipx_search_aspect. q_src is [nq, d] (A == 0) or [nq, A, d].
@@ -529,7 +563,8 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
         IPX_HIP(hipMemsetAsync(ix->err.p, 0, 256, st));
         // bf16 scan when the index keeps a bf16 copy; with fp32 rows at hand, depths whose
         // 4k candidates exceed the list limit go straight to the fp32 scan
-        const bool bf16 = ix->storage == 2 || (ix->storage == 1 && (4 * k <= IPX_MAX_K || ix->force_kc > 0));
+        const bool bf16 = ix->storage == 2 ||
+                          (ix->storage == 1 && !ix->force_f32_scan && (4 * k <= IPX_MAX_K || ix->force_kc > 0));
         int rc = bf16 ? scan_bf16_path(ix, dq, dw, A, logits, nq, k, dD, dI, st)
                       : scan_f32_path(ix, dq, dw, A, logits, nq, k, dD, dI, st, true);
         if (rc) return rc;
@@ -720,6 +755,11 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
             return fail(IPX_ERR_STATE, "set_param: storage can only be chosen while the index is empty and unreserved");
         if (value != 0 && ix->d > 8192) return fail(IPX_ERR_ARG, "set_param: bf16 storage needs d <= 8192");
         ix->storage = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "f32_scan")) {
+        if (value && ix->storage == 2) return fail(IPX_ERR_STATE, "set_param: f32_scan needs fp32 rows (storage 0 or 1)");
+        ix->force_f32_scan = value != 0;
         return 0;
     }
     if (!strcmp(name, "bf16_candidates")) {

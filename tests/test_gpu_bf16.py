@@ -1,0 +1,189 @@
+"""GPU parity of the bf16 scan + exact fp32 rescoring modes (include/ipx.h, "storage" 1 and 2).
+
+The bar is the fp32 path's own: storage 1 ("bf16scan") must return the SAME BITS as the fp32 scan
+(scores and ids), whatever the candidate-list length, because every query either passes the
+sufficiency check of rescore_kernel or is repeated on a longer list / the fp32 scan. Storage 2
+("bf16") is exact on the bf16-rounded rows: bit-identical to the oracle's kernel-order scores of
+<fp32 query, rounded row>.
+"""
+import numpy as np
+import pytest
+
+from conftest import gaussian
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+FLT_MAX = np.finfo(np.float32).max
+
+
+@pytest.fixture(scope="module")
+def R():
+    from mural_amd.faiss_retriever import retriever
+    from mural_amd import _lib
+    assert _lib.lib().ipx_device_count() >= 1, "no HIP device visible: the search path has no CPU fallback"
+    return retriever
+
+
+def bf16_round(x):
+    """round-to-nearest-even fp32 -> bf16 -> fp32 (finite inputs)"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32)
+
+
+def index(R, X, storage, adds=1):
+    ix = R.FlatIPIndex(X.shape[1], storage=storage)
+    step = -(-X.shape[0] // adds) if X.shape[0] else 1
+    for lo in range(0, X.shape[0], step):
+        ix.add(X[lo:lo + step])
+    assert ix.ntotal == X.shape[0]
+    return ix
+
+
+def assert_bits(D, I, Q, X, k):
+    rD, rI = O.topk_total_order(O.scores_mfma_order(Q, X), k)
+    assert np.array_equal(I, rI), f"ids differ at {np.argwhere(I != rI)[:3].tolist()}"
+    assert np.array_equal(D.view(np.uint32), rD.view(np.uint32)), "score bits differ"
+
+
+@pytest.mark.parametrize("n,d,nq,k,adds", [
+    (4096, 768, 32, 1, 1), (4096, 768, 32, 100, 1), (5000, 768, 300, 100, 2),
+    (20000, 100, 513, 100, 3),        # d not a multiple of 32, three adds, three query blocks
+    (9000, 17, 64, 512, 2),           # 4k = 2048 candidates: the longest list
+    (9000, 48, 64, 1000, 1),          # 4k > limit: storage 1 goes straight to the fp32 scan
+    (777, 768, 1, 100, 1), (255, 16, 257, 5, 1), (257, 16, 256, 300, 1), (1, 8, 3, 4, 1),
+])
+def test_bf16scan_is_bit_identical_to_the_fp32_scan(R, n, d, nq, k, adds):
+    X, Q = gaussian(1234, (n, d)), gaussian(4321, (nq, d))
+    ix = index(R, X, "bf16scan", adds)
+    D, I = ix.search(Q, k)
+    assert D.dtype == np.float32 and I.dtype == np.int64 and D.shape == (nq, k) == I.shape
+    assert_bits(D, I, Q, X, k)
+    st = ix.last_bf16_stats()
+    assert (st["candidates"] > 0) == (4 * k <= 2048)
+    # same index, fp32 scan forced: the two scans of one index agree bit for bit
+    ix.set_param("f32_scan", 1)
+    D2, I2 = ix.search(Q, k)
+    assert np.array_equal(I, I2) and np.array_equal(D.view(np.uint32), D2.view(np.uint32))
+    assert ix.last_bf16_stats()["candidates"] == 0
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(4096, 768, 32, 10), (30000, 768, 300, 100), (20000, 100, 513, 100),
+                                      (9000, 17, 64, 1000), (300, 64, 20, 500)])
+def test_bf16_rows_exact_on_the_stored_values(R, n, d, nq, k):
+    X, Q = gaussian(11, (n, d)), gaussian(12, (nq, d))
+    Xr = bf16_round(X)
+    ix = index(R, X, "bf16")
+    D, I = ix.search(Q, k)
+    assert_bits(D, I, Q, Xr, k)
+    assert O.check_topk(D, I, Q, Xr, k) == []
+    # rows that are already bf16 (as float16-free torch tensors) are kept exactly
+    import torch
+    t = torch.from_numpy(Xr).to("cuda:0").to(torch.bfloat16)
+    ix2 = R.FlatIPIndex(d, storage="bf16")
+    ix2.add(t)
+    D2, I2 = ix2.search(Q, k)
+    assert np.array_equal(I, I2) and np.array_equal(D.view(np.uint32), D2.view(np.uint32))
+
+
+def test_short_candidate_lists_are_caught_and_repeated(R):
+    # many near-ties: rows are small perturbations of one vector, so far more than kc rows sit
+    # inside the bf16 error margin of the k-th score. With the shortest list every query fails
+    # the check; the answer must not change.
+    rng = np.random.default_rng(5)
+    d, n, nq, k = 64, 30000, 40, 10
+    base = rng.standard_normal(d).astype(np.float32)
+    X = (base[None, :] + 1e-3 * rng.standard_normal((n, d))).astype(np.float32)
+    Q = (base[None, :] + 0.1 * rng.standard_normal((nq, d))).astype(np.float32)
+    ix = index(R, X, "bf16scan")
+    ix.set_param("bf16_candidates", 16)
+    D, I = ix.search(Q, k)
+    assert_bits(D, I, Q, X, k)
+    assert ix.last_bf16_stats()["fallback_queries"] == nq
+    # bf16-only storage has nothing exact to fall back on: the longest list is tried, then a clear error
+    ix2 = index(R, X, "bf16")
+    ix2.set_param("bf16_candidates", 16)
+    from mural_amd._lib import IpxError
+    try:
+        D2, I2 = ix2.search(Q, k)
+        assert_bits(D2, I2, Q, bf16_round(X), k)      # the 2048-long retry was enough
+    except IpxError as e:
+        assert e.code == 4 and "near-ties" in str(e)
+
+
+def test_bf16_edge_cases(R):
+    # k > ntotal, empty index, ties, NaN / inf rows (they poison the norm bound: everything falls back)
+    X, Q = gaussian(1, (37, 64)), gaussian(2, (25, 64))
+    for storage, ref in (("bf16scan", X), ("bf16", bf16_round(X))):
+        ix = index(R, X, storage)
+        D, I = ix.search(Q, 100)
+        assert (I[:, 37:] == -1).all() and (D[:, 37:] == -FLT_MAX).all()
+        assert_bits(D, I, Q, ref, 100)
+        e = R.FlatIPIndex(64, storage=storage)
+        D, I = e.search(Q, 7)
+        assert (I == -1).all() and (D == -FLT_MAX).all()
+    base = gaussian(3, (300, 32))
+    X = np.concatenate([base, base, base[:50]], axis=0)
+    Q = gaussian(4, (40, 32))
+    ix = index(R, X, "bf16scan")
+    D, I = ix.search(Q, 9)
+    assert_bits(D, I, Q, X, 9)
+    assert (I[:, 0] < 300).all() and np.array_equal(D[:, 0], D[:, 1])
+    X = gaussian(7, (5000, 16))
+    X[5, 0] = np.nan
+    X[11, 3] = np.inf
+    X[12, 3] = -np.inf
+    Q = gaussian(8, (30, 16))
+    ix = index(R, X, "bf16scan")
+    D, I = ix.search(Q, 20)
+    assert_bits(D, I, Q, X, 20)
+    assert not (I == 5).any()
+
+
+def test_bf16scan_aspect_queries_and_float16_rows(R):
+    n, d, nq, A = 5000, 768, 70, 3
+    X = gaussian(51, (n, d)).astype(np.float16)
+    E = gaussian(52, (nq, A, d))
+    logits = gaussian(53, (nq, A))
+    a = R.FlatIPIndex(d, storage="f32")
+    a.add(X)
+    b = R.FlatIPIndex(d, storage="bf16scan")
+    b.add(X)
+    for kw in ({"logits": True},):
+        D0, I0 = a.search_aspect(E, logits, 100, **kw)
+        D1, I1 = b.search_aspect(E, logits, 100, **kw)
+        assert b.last_bf16_stats()["candidates"] == 400
+        assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
+
+
+def test_storage_can_only_be_chosen_on_an_empty_index(R):
+    from mural_amd._lib import IpxError
+    ix = R.FlatIPIndex(16)
+    ix.add(gaussian(1, (10, 16)))
+    with pytest.raises(IpxError):
+        ix.set_param("storage", 1)
+    with pytest.raises(IpxError):
+        R.FlatIPIndex(16, storage="bf16").set_param("f32_scan", 1)
+
+
+def test_config2_scale_bf16scan_equals_fp32_scan(R):
+    """BASELINE.json configs[1] size (1.8M x 768, 8192 queries, top-100): both scans of one
+    storage-1 index return the same bits; storage 2 agrees with a float64 recomputation."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    n, d, nq, k = 1_800_000, 768, 8192, 100
+    ix = R.FlatIPIndex(d, device=0, storage="bf16scan")
+    ix.reserve(n)
+    for lo in range(0, n, 300_000):
+        ix.add(torch.randn((300_000, d), generator=g, device=dev, dtype=torch.float32))
+    g.manual_seed(4321)
+    Q = torch.randn((nq, d), generator=g, device=dev, dtype=torch.float32)
+    D1, I1 = ix.search_device(Q, k)
+    st = ix.last_bf16_stats()
+    assert st["candidates"] == 400 and st["fallback_queries"] < nq // 50
+    ix.set_param("f32_scan", 1)
+    D0, I0 = ix.search_device(Q, k)
+    ix.check()
+    assert torch.equal(I0, I1) and torch.equal(D0.view(torch.int32), D1.view(torch.int32))
