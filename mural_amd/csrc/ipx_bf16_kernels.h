@@ -3,7 +3,7 @@
 // The scan kernel finds, per query, the K' > k rows with the largest APPROXIMATE scores
 // (bf16-rounded operands, v_mfma_f32_32x32x16_bf16, fp32 accumulation); rescore_kernel then
 // recomputes those rows' scores exactly — the same ordered fp32 fmaf chain the fp32 scan kernel
-// produces (ipx_kernels.h / oracle orc_scores_mfma_order) — and keeps the best k. The result is
+// produces (ipx_kernels.h) — and keeps the best k. The result is
 // PROVABLY the fp32 result whenever the candidate list is long enough, which rescore_kernel
 // checks per query (see margin rule there); queries that fail the check are flagged and the host
 // repeats them on the fp32 scan. So faiss.IndexFlatIP semantics (retriever.py:19) are unchanged.
