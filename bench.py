@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-splits", type=int, default=0, help="diagnostic: cap the corpus splits per query block")
     ap.add_argument("--storage", choices=["f32", "bf16scan", "bf16"], default="f32",
                     help="f32: fp32 MFMA scan (headline); bf16scan: bf16 MFMA scan + exact fp32 rescoring "
                          "(bit-identical results); bf16: bf16 rows only")
@@ -110,6 +111,8 @@ def main():
     Q = torch.randn((nq, d), generator=g, device=dev, dtype=torch.float32)
 
     ix.set_timing(True)
+    if args.max_splits:
+        ix.set_param("max_splits", args.max_splits)
 
     def barrier():
         torch.cuda.synchronize()

@@ -84,6 +84,7 @@ struct ipx_index {
     int64_t last_fallback = 0;       // queries the last search repeated on the fp32 scan
     int max_splits = 0;      // 0 = automatic
     int force_kc = 0;        // 0 = automatic candidate count
+    bool no_small_batch = false;   // diagnostic: always use the 256-query bf16 scan variant
     bool force_f32_scan = false;   // storage 1: use the fp32 scan although a bf16 copy exists
     size_t tile_bytes() const { return (size_t)nks * ipx::STAGE_A_BYTES; }
     size_t tile_bytes_h() const { return (size_t)nks_h * ipx::HSTAGE_A; }
@@ -144,13 +145,13 @@ int grow_corpus_h(ipx_index* ix, int64_t need_tiles, hipStream_t st) {
 }
 
 int launch_pack_bf16(const void* src, int dtype, int64_t n, int64_t n_pad, int d, uint16_t* dst, int64_t row0,
-                     int nks_h, hipStream_t st) {
+                     int rows_per_tile, int nks_h, hipStream_t st) {
     const int64_t total = n_pad * nks_h * 4;
     if (total == 0) return 0;
     const int64_t blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return fail(IPX_ERR_ARG, "pack: too many rows in one call");
     hipLaunchKernelGGL(ipx::pack_rows_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dtype, n, n_pad, d,
-                       dst, row0, nks_h);
+                       dst, row0, rows_per_tile, nks_h);
     IPX_HIP(hipGetLastError());
     return 0;
 }
@@ -172,7 +173,7 @@ int add_device_rows(ipx_index* ix, const void* rows, int dtype, int64_t m, int64
     if (ix->storage != 2)
         if (int rc = launch_pack(rows, dtype, m, m, ix->d, ix->Xp, row0, ipx::BD, ix->nks, nullptr, 0, 0, st)) return rc;
     if (ix->storage != 0) {
-        if (int rc = launch_pack_bf16(rows, dtype, m, m, ix->d, ix->Xh, row0, ix->nks_h, st)) return rc;
+        if (int rc = launch_pack_bf16(rows, dtype, m, m, ix->d, ix->Xh, row0, ipx::HBD, ix->nks_h, st)) return rc;
         // the margin bound uses |x|_2 of the values the exact score is defined on: the fp32 rows
         // (storage 1) or the stored bf16 rows (storage 2; rounding can only matter upwards by 2^-8)
         const int blocks = (int)std::min<int64_t>((m + 3) / 4, 4096);
@@ -283,7 +284,7 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
         // partials are [nq][S][k]: shard stride k, query stride S*k; lists arrive sorted
         hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st,
                            (const float*)ix->partD.p, (const int64_t*)ix->partI.p, S, nq, k, k, P, 1,
-                           (int64_t)k, (int64_t)S * k, dD, dI);
+                           (int64_t)k, (int64_t)S * k, dD, dI, (const int*)nullptr);
         IPX_HIP(hipGetLastError());
         if (record) {
             IPX_HIP(hipEventRecord(ix->ev[3], st));
@@ -321,7 +322,11 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, float* 
     const size_t ncand = (size_t)nq * kc;
     const bool timing = primary && ix->timing;
 
-    const int nqb = (int)((nq + ipx::BQ - 1) / ipx::BQ);
+    // up to 64 queries: the 64-query variant (a quarter of the MFMA work per corpus byte)
+    const bool small = nq <= 64 && !ix->no_small_batch;
+    const int bq = small ? 64 : 256;
+    const int stage_b = bq * 64;
+    const int nqb = (int)((nq + bq - 1) / bq);
     const int ntiles = (int)((N + ipx::HBD - 1) / ipx::HBD);
     hipDeviceProp_t prop;
     IPX_HIP(hipGetDeviceProperties(&prop, ix->device));
@@ -334,11 +339,11 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, float* 
     const int G = nqb * S;
     // queue: kc survivors of a compaction + 2 tiles of appends before the next one runs + room to fill
     const int cap = next_pow2(kc + 2 * ipx::HBD + kc / 2);
-    const int ring = ipx::HNBUF * ipx::HSTAGE;
+    const int ring = small ? ipx::HCfg<1>::RING : ipx::HCfg<4>::RING;
     const int nsortwaves = std::max(1, std::min(8, ring / (cap * 8)));
 
-    if (int rc = ix->Qp.ensure((size_t)nqb * nks * ipx::HSTAGE_B)) return rc;
-    if (int rc = ix->cand.ensure((size_t)G * ipx::BQ * cap * sizeof(uint64_t))) return rc;
+    if (int rc = ix->Qp.ensure((size_t)nqb * nks * stage_b)) return rc;
+    if (int rc = ix->cand.ensure((size_t)G * bq * cap * sizeof(uint64_t))) return rc;
     if (int rc = ix->err.ensure(256)) return rc;
     if (int rc = ix->candD.ensure(ncand * sizeof(float))) return rc;
     if (int rc = ix->candI.ensure(ncand * sizeof(int64_t))) return rc;
@@ -348,12 +353,12 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, float* 
         if (int rc = ix->partI.ensure(ncand * S * sizeof(int64_t))) return rc;
     }
     const size_t ctr_bytes = ((size_t)nqb * sizeof(uint32_t) + 255) / 256 * 256;
-    const size_t pub_bytes = ctr_bytes + (size_t)G * ipx::BQ * sizeof(uint32_t);
+    const size_t pub_bytes = ctr_bytes + (size_t)G * bq * sizeof(uint32_t);
     if (int rc = ix->pub.ensure(pub_bytes)) return rc;
     IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
 
     if (timing) IPX_HIP(hipEventRecord(ix->ev[0], st));
-    if (int rc = launch_pack_bf16(qf, IPX_F32, nq, (int64_t)nqb * ipx::BQ, d, (uint16_t*)ix->Qp.p, 0, nks, st)) return rc;
+    if (int rc = launch_pack_bf16(qf, IPX_F32, nq, (int64_t)nqb * bq, d, (uint16_t*)ix->Qp.p, 0, bq, nks, st)) return rc;
     if (timing) IPX_HIP(hipEventRecord(ix->ev[1], st));
 
     ipx::ScanParams p;
@@ -368,6 +373,11 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, float* 
     p.run_tiles = R;
     p.r = (kc + S - 1) / S;
     p.trace = nullptr;
+    if (ix->trace_on && primary) {
+        if (int rc = ix->trace.ensure((size_t)G * 20 * sizeof(uint64_t))) return rc;
+        IPX_HIP(hipMemsetAsync(ix->trace.p, 0, (size_t)G * 4 * sizeof(uint64_t), st));
+        p.trace = (uint64_t*)ix->trace.p;
+    }
     p.N = N;
     p.id_base = ix->id_base;
     p.nq = (int)nq;
@@ -377,8 +387,13 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, float* 
     p.S = S;
     p.ntiles = ntiles;
     const int lds = std::max(ring, nsortwaves * cap * 8) + ipx::LDS_STATE_BYTES;
-    IPX_HIP(hipFuncSetAttribute((const void*)ipx::scan_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(ipx::scan_bf16_kernel, dim3(G), dim3(ipx::HTHREADS), lds, st, p, nsortwaves);
+    if (small) {
+        IPX_HIP(hipFuncSetAttribute((const void*)ipx::scan_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(ipx::scan_bf16_kernel<1>, dim3(G), dim3(ipx::HTHREADS), lds, st, p, nsortwaves);
+    } else {
+        IPX_HIP(hipFuncSetAttribute((const void*)ipx::scan_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(ipx::scan_bf16_kernel<4>, dim3(G), dim3(ipx::HTHREADS), lds, st, p, nsortwaves);
+    }
     IPX_HIP(hipGetLastError());
     if (timing) IPX_HIP(hipEventRecord(ix->ev[2], st));
 
@@ -388,9 +403,19 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, float* 
         if (mlds > 64 * 1024)
             IPX_HIP(hipFuncSetAttribute((const void*)ipx::merge_topk_kernel,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, mlds));
+        // many lists (few queries spread over every CU): cut by the union bound and sort once;
+        // the fold kernel then only serves queries whose pool overflowed
+        const int* todo = nullptr;
+        if (S >= 16) {
+            hipLaunchKernelGGL(ipx::merge_pool_kernel, dim3((unsigned)nq), dim3(256), 0, st, (const float*)ix->partD.p,
+                               (const int64_t*)ix->partI.p, S, kc, kc, (int64_t)kc, (int64_t)S * kc,
+                               (float*)ix->candD.p, (int64_t*)ix->candI.p, (int*)ix->flags.p);
+            IPX_HIP(hipGetLastError());
+            todo = (const int*)ix->flags.p;
+        }
         hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st,
                            (const float*)ix->partD.p, (const int64_t*)ix->partI.p, S, nq, kc, kc, P, 1,
-                           (int64_t)kc, (int64_t)S * kc, (float*)ix->candD.p, (int64_t*)ix->candI.p);
+                           (int64_t)kc, (int64_t)S * kc, (float*)ix->candD.p, (int64_t*)ix->candI.p, todo);
         IPX_HIP(hipGetLastError());
     }
     if (timing) {
@@ -729,7 +754,7 @@ int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in
     if (e == hipSuccess) {
         // inputs are [S][nq][k_in]: shard stride nq*k_in, query stride k_in; order not assumed
         hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st, dD, dI, S, nq, k_in, k_out,
-                           P, 0, (int64_t)nq * k_in, (int64_t)k_in, oD, oI);
+                           P, 0, (int64_t)nq * k_in, (int64_t)k_in, oD, oI, (const int*)nullptr);
         e = hipGetLastError();
     }
     if (e == hipSuccess && !on_device) {
@@ -755,6 +780,10 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
             return fail(IPX_ERR_STATE, "set_param: storage can only be chosen while the index is empty and unreserved");
         if (value != 0 && ix->d > 8192) return fail(IPX_ERR_ARG, "set_param: bf16 storage needs d <= 8192");
         ix->storage = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "no_small_batch")) {
+        ix->no_small_batch = value != 0;
         return 0;
     }
     if (!strcmp(name, "f32_scan")) {

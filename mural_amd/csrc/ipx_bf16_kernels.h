@@ -63,7 +63,7 @@ fuse_aspect_kernel(const float* __restrict__ src, const float* __restrict__ w, i
 // One thread per (row, 16-byte chunk of 8 bf16).
 __global__ void __launch_bounds__(256)
 pack_rows_bf16_kernel(const void* __restrict__ src, int dtype, int64_t n, int64_t n_pad, int d,
-                      uint16_t* __restrict__ dst, int64_t row0, int nks) {
+                      uint16_t* __restrict__ dst, int64_t row0, int rows_per_tile, int nks) {
     const int nchunks = nks * 4;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t r = gid / nchunks;
@@ -81,10 +81,10 @@ pack_rows_bf16_kernel(const void* __restrict__ src, int dtype, int64_t n, int64_
             }
     }
     const int64_t R = row0 + r;
-    const int64_t tile = R / HBD;
-    const int rr = (int)(R - tile * HBD);
+    const int64_t tile = R / rows_per_tile;
+    const int rr = (int)(R - tile * rows_per_tile);
     const int ks = c >> 2, pc = (c & 3) ^ ((rr >> 2) & 3);
-    uint16_t* o = dst + ((tile * nks + ks) * HBD + rr) * 32 + pc * 8;
+    uint16_t* o = dst + ((tile * nks + ks) * rows_per_tile + rr) * 32 + pc * 8;
     uint4 out;
     out.x = v[0] | ((uint32_t)v[1] << 16);
     out.y = v[2] | ((uint32_t)v[3] << 16);
@@ -120,38 +120,86 @@ row_sumsq_max_kernel(const void* __restrict__ src, int dtype, int64_t n, int d, 
 // ---- bf16 scan ---------------------------------------------------------------------------------
 #define IPX_DS_READ_B128(dst, addr, off) \
     asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
-
-__device__ __forceinline__ void issue_stage_bf16(const ScanParams& p, char* buf, int64_t tile, int qb,
-                                                 int ks, int wave, int lane) {
-    // A stage and B stage: 16 KiB contiguous each = 2 rounds of 8 waves x 1 KiB
-    const char* ga = (const char*)p.Xp + ((size_t)tile * p.nks + ks) * HSTAGE_A + wave * 1024 + lane * 16;
-    const char* gb = (const char*)p.Qp + ((size_t)qb * p.nks + ks) * HSTAGE_B + wave * 1024 + lane * 16;
-    char* la = buf + wave * 1024;
-    char* lb = buf + HSTAGE_A + wave * 1024;
-#define IPX_GLDS(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g), \
-                                                         (__attribute__((address_space(3))) void*)(l), 16, 0, 0)
-    IPX_GLDS(ga, la);
-    IPX_GLDS(ga + 8192, la + 8192);
-    IPX_GLDS(gb, lb);
-    IPX_GLDS(gb + 8192, lb + 8192);
-#undef IPX_GLDS
-}
+#define IPX_GLDS(g_, l_) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g_), \
+                                                           (__attribute__((address_space(3))) void*)(l_), 16, 0, 0)
 
 __device__ __forceinline__ bf16x8 as_bf16x8(f32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
+// Geometry of one scan variant. QW = 32-query groups per wave: 4 -> 256 queries per workgroup
+// (large batches, MFMA-bound), 1 -> 64 queries per workgroup (small batches: a quarter of the
+// MFMA work per corpus byte and a deeper ring, so the corpus stream, not the matrix core, sets
+// the pace — the HBM-bound regime of BASELINE.json configs[4]).
+template <int QW> struct HCfg {
+    static constexpr int BQ_ = 64 * QW;                  // queries per workgroup (2 wave columns)
+    static constexpr int STAGE_B = BQ_ * 64;
+    static constexpr int STAGE = HSTAGE_A + STAGE_B;     // 32 KiB / 20 KiB
+    static constexpr int NBUF = QW == 4 ? 4 : 6;         // LDS stage ring
+    static constexpr int LOADS = QW == 4 ? 4 : 3;        // LDS-DMA pieces per thread per stage
+    static constexpr int RING = NBUF * STAGE;
+};
+
+template <int QW>
+__device__ __forceinline__ void issue_stage_bf16(const ScanParams& p, char* buf, int64_t tile, int qb,
+                                                 int ks, int wave, int lane) {
+    using C = HCfg<QW>;
+    // A stage: 16 KiB contiguous = 2 rounds of 8 waves x 1 KiB. B stage: 16 KiB likewise, or
+    // 4 KiB = one round in which waves 4..7 repeat the pieces of waves 0..3 (same bytes to the
+    // same place: every wave issues the same number of copies, so one vmcnt serves all).
+    const char* ga = (const char*)p.Xp + ((size_t)tile * p.nks + ks) * HSTAGE_A + wave * 1024 + lane * 16;
+    char* la = buf + wave * 1024;
+    IPX_GLDS(ga, la);
+    IPX_GLDS(ga + 8192, la + 8192);
+    const int wb = QW == 4 ? wave : (wave & 3);
+    const char* gb = (const char*)p.Qp + ((size_t)qb * p.nks + ks) * C::STAGE_B + wb * 1024 + lane * 16;
+    char* lb = buf + HSTAGE_A + wb * 1024;
+    IPX_GLDS(gb, lb);
+    if (QW == 4) IPX_GLDS(gb + 8192, lb + 8192);
+}
+
+template <int BQ_>
+__device__ __forceinline__ void poll_union_threshold_n(const ScanParams& p, float* taus, int qb, int tid) {
+    if (p.S <= 1) return;
+    const uint32_t* col = p.pub + (size_t)qb * p.S * BQ_ + tid;
+    uint32_t v = 0xffffffffu;
+    for (int s2 = 0; s2 < p.S; ++s2) {
+        const uint32_t x = __hip_atomic_load(col + (size_t)s2 * BQ_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = x < v ? x : v;
+    }
+    if (v != 0) taus[tid] = fmaxf(taus[tid], f32_below(f32_unordered(v)));
+}
+
+template <int QW>
+__device__ __forceinline__ void read_set(f32x4 (&a)[2], f32x4 (&b)[QW], uint32_t aa, uint32_t bb) {
+    IPX_DS_READ_B128(a[0], aa, 0); IPX_DS_READ_B128(a[1], aa, 2048);
+    IPX_DS_READ_B128(b[0], bb, 0);
+    if constexpr (QW == 4) {
+        IPX_DS_READ_B128(b[1], bb, 2048); IPX_DS_READ_B128(b[2], bb, 4096); IPX_DS_READ_B128(b[3], bb, 6144);
+    }
+}
+// s_waitcnt lgkmcnt(N) that the compiler sees as producing the operand registers
+template <int QW, int N>
+__device__ __forceinline__ void wait_set(f32x4 (&a)[2], f32x4 (&b)[QW]) {
+    if constexpr (QW == 4)
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]) : "n"(N) : "memory");
+}
+
 // Same streaming top-k machinery as scan_f32_kernel (queues, thresholds, compaction episodes,
-// union threshold, dynamic runs); only the tile shape, the stage ring and the MFMA differ.
-// The pipeline keeps HNBUF - 1 stages in flight with counted vmcnt waits; the operand reads are
-// issued from asm (a compiler-visible LDS read after an LDS-DMA copy would get a vmcnt(0)).
+// union threshold); the tile shape, the stage ring and the MFMA differ. The pipeline keeps
+// NBUF - 1 stages in flight with counted vmcnt waits; the operand reads are issued from asm
+// (a compiler-visible LDS read after an LDS-DMA copy would get a vmcnt(0)).
+template <int QW>
 __global__ void __launch_bounds__(HTHREADS)
 scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
+    using C = HCfg<QW>;
+    constexpr int BQ_ = C::BQ_, NBUF = C::NBUF, STAGE = C::STAGE, LOADS = C::LOADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int scratch_bytes = nsortwaves * p.cap * 8;
-    const int stage_region = scratch_bytes > HNBUF * HSTAGE ? scratch_bytes : HNBUF * HSTAGE;
+    const int stage_region = scratch_bytes > C::RING ? scratch_bytes : C::RING;
     int* cnts = (int*)(smem + stage_region);
-    float* taus = (float*)(smem + stage_region + BQ * 4);
-    int* flags = (int*)(smem + stage_region + 2 * BQ * 4);
-    int* runslot = flags + 2;
+    float* taus = (float*)(smem + stage_region + BQ_ * 4);
+    int* flags = (int*)(smem + stage_region + 2 * BQ_ * 4);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -161,33 +209,32 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int qb = logical / p.S, split = logical - qb * p.S;
 
-    if (tid < BQ) {
+    if (tid < BQ_) {
         cnts[tid] = 0;
-        taus[tid] = ((int64_t)qb * BQ + tid < p.nq) ? -FLT_MAX : INFINITY;
+        taus[tid] = ((int64_t)qb * BQ_ + tid < p.nq) ? -FLT_MAX : INFINITY;
     }
     if (tid < 2) flags[tid] = 0;
-    uint32_t* mypub = p.S > 1 ? p.pub + ((size_t)qb * p.S + split) * BQ : nullptr;
+    uint32_t* mypub = p.S > 1 ? p.pub + ((size_t)qb * p.S + split) * BQ_ : nullptr;
     const int fill_limit = p.cap - 2 * HBD;
 
-    uint64_t* myqueues = p.cand + (size_t)blockIdx.x * BQ * p.cap;
+    uint64_t* myqueues = p.cand + (size_t)blockIdx.x * BQ_ * p.cap;
     uint64_t* scratch = (uint64_t*)smem + (size_t)wave * p.cap;
 
     const int sw = (lane >> 2) & 3;
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const uint32_t a_off = (wd * 64 + l31) * 64;
-    const uint32_t b_off = HSTAGE_A + (wq * 128 + l31) * 64;
+    const uint32_t b_off = HSTAGE_A + (wq * (32 * QW) + l31) * 64;
     const uint32_t pc0 = ((0 + h) ^ sw) * 16, pc1 = ((2 + h) ^ sw) * 16;
 
     const int R = p.run_tiles;
     int adv_end = (split + 1) * R < p.ntiles ? (split + 1) * R : p.ntiles;
     int nxt = -1, enter_t = -1;
+    // Runs are dealt round-robin: split s takes runs s, s + S, s + 2S, ... (one workgroup per CU
+    // here, so there are no fast / slow pairs to balance dynamically as in the fp32 kernel).
+    int my_run = split;
     auto claim_next_run = [&]() {
-        if (tid == 0) {
-            const uint32_t run = (uint32_t)p.S + atomicAdd(p.run_ctr + qb, 1u);
-            *runslot = (int64_t)run * R < p.ntiles ? (int)(run * R) : -1;
-        }
-        __syncthreads();
-        nxt = *runslot;
+        my_run += p.S;
+        nxt = (int64_t)my_run * R < p.ntiles ? my_run * R : -1;
         enter_t = -1;
     };
     auto advance = [&](StageCursor c) {
@@ -207,88 +254,122 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
         return c;
     };
 
-    // cur[0] = stage being computed, cur[1..HNBUF-1] = in flight, cur[HNBUF] = next to issue
-    StageCursor cur[HNBUF + 1];
-    cur[0] = StageCursor{split * R, 0, true};
+    // cur[0] = stage being computed (ring slot `slot`), cur[1..NBUF-1] = in flight, cur[NBUF] = next to issue
+    StageCursor cur[NBUF + 1];
+    cur[0] = StageCursor{split * R, 0, split * R < p.ntiles};
     claim_next_run();
 #pragma unroll
-    for (int i = 1; i <= HNBUF; ++i) cur[i] = advance(cur[i - 1]);
+    for (int i = 1; i <= NBUF; ++i) cur[i] = advance(cur[i - 1]);
 #pragma unroll
-    for (int i = 0; i < HNBUF; ++i) issue_stage_bf16(p, smem + i * HSTAGE, cur[i].t, qb, cur[i].ks, wave, lane);
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HLOADS * (HNBUF - 1)) : "memory");
+    for (int i = 0; i < NBUF; ++i) issue_stage_bf16<QW>(p, smem + i * STAGE, cur[i].t, qb, cur[i].ks, wave, lane);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 1)) : "memory");
     __syncthreads();
 
-    f32x4 a0[2], b0[4], a1[2], b1[4];
-    {
-        const uint32_t aa = smem_base + a_off + pc0, bb = smem_base + b_off + pc0;
-        IPX_DS_READ_B128(a0[0], aa, 0); IPX_DS_READ_B128(a0[1], aa, 2048);
-        IPX_DS_READ_B128(b0[0], bb, 0); IPX_DS_READ_B128(b0[1], bb, 2048);
-        IPX_DS_READ_B128(b0[2], bb, 4096); IPX_DS_READ_B128(b0[3], bb, 6144);
-    }
+    f32x4 a0[2], b0[QW], a1[2], b1[QW];
+    read_set<QW>(a0, b0, smem_base + a_off + pc0, smem_base + b_off + pc0);
 
-    int g = 0, tiles_done = 0;
+    int slot = 0, tiles_done = 0;
+    // optional trace (ipx_set_param "trace"): wave 0's view of where the time goes
+    uint64_t tr_epi = 0, tr_sort = 0, tr_begin = 0;
+    uint32_t tr_appends = 0, tr_episodes = 0;
+    if (p.trace) tr_begin = __builtin_readcyclecounter();
     while (cur[0].ok) {
         const int t = cur[0].t;
         if (t == enter_t) claim_next_run();
-        f32x16 acc[2][4];
+        f32x16 acc[2][QW];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < QW; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        for (int ks = 0; ks < p.nks; ++ks, ++g) {
-            const uint32_t buf = smem_base + (g & (HNBUF - 1)) * HSTAGE;
-            const uint32_t nbuf = smem_base + ((g + 1) & (HNBUF - 1)) * HSTAGE;
-            {
-                const uint32_t aa = buf + a_off + pc1, bb = buf + b_off + pc1;
-                IPX_DS_READ_B128(a1[0], aa, 0); IPX_DS_READ_B128(a1[1], aa, 2048);
-                IPX_DS_READ_B128(b1[0], bb, 0); IPX_DS_READ_B128(b1[1], bb, 2048);
-                IPX_DS_READ_B128(b1[2], bb, 4096); IPX_DS_READ_B128(b1[3], bb, 6144);
-            }
+        for (int ks = 0; ks < p.nks; ++ks) {
+            const int nslot = slot + 1 == NBUF ? 0 : slot + 1;
+            const uint32_t buf = smem_base + slot * STAGE;
+            const uint32_t nbuf = smem_base + nslot * STAGE;
+            read_set<QW>(a1, b1, buf + a_off + pc1, buf + b_off + pc1);
             // set 0 of this stage was read one half-stage ago
-            asm volatile("s_waitcnt lgkmcnt(6)"
-                         : "+v"(a0[0]), "+v"(a0[1]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]) :: "memory");
+            wait_set<QW, 2 + QW>(a0, b0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < QW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0[i]), as_bf16x8(b0[j]), acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             // set 1 is in registers (so nobody reads this stage's buffer any more), the next
-            // stage has landed (HNBUF - 2 younger stages may still be in flight)
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(a1[0]), "+v"(a1[1]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]) :: "memory");
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HLOADS * (HNBUF - 2)) : "memory");
+            // stage has landed (NBUF - 2 younger stages may still be in flight)
+            wait_set<QW, 0>(a1, b1);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            issue_stage_bf16(p, smem + (g & (HNBUF - 1)) * HSTAGE, cur[HNBUF].t, qb, cur[HNBUF].ks, wave, lane);
+            // second half, in pinned issue order: the next stage's set-0 reads first (they have the
+            // whole half to land), then the copy pieces of the stage NBUF ahead spread among the
+            // MFMAs — a piece costs the wave ~60-180 issue cycles, which the matrix core spends on
+            // the MFMAs already queued (and on the other wave of this SIMD)
+            read_set<QW>(a0, b0, nbuf + a_off + pc0, nbuf + b_off + pc0);
             {
-                const uint32_t aa = nbuf + a_off + pc0, bb = nbuf + b_off + pc0;
-                IPX_DS_READ_B128(a0[0], aa, 0); IPX_DS_READ_B128(a0[1], aa, 2048);
-                IPX_DS_READ_B128(b0[0], bb, 0); IPX_DS_READ_B128(b0[1], bb, 2048);
-                IPX_DS_READ_B128(b0[2], bb, 4096); IPX_DS_READ_B128(b0[3], bb, 6144);
+                const StageCursor cn = cur[NBUF];
+                const char* ga = (const char*)p.Xp + ((size_t)cn.t * p.nks + cn.ks) * HSTAGE_A + wave * 1024 + lane * 16;
+                const int wb = QW == 4 ? wave : (wave & 3);
+                const char* gb = (const char*)p.Qp + ((size_t)qb * p.nks + cn.ks) * C::STAGE_B + wb * 1024 + lane * 16;
+                char* la = smem + slot * STAGE + wave * 1024;
+                char* lb = smem + slot * STAGE + HSTAGE_A + wb * 1024;
+#define IPX_MFMA1(i_, j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[i_]), as_bf16x8(b1[j_]), acc[i_][j_], 0, 0, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (QW == 4) {
+                    IPX_MFMA1(0, 0); IPX_MFMA1(0, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IPX_GLDS(ga, la);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IPX_MFMA1(0, 2); IPX_MFMA1(0, 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IPX_GLDS(ga + 8192, la + 8192);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IPX_MFMA1(1, 0); IPX_MFMA1(1, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IPX_GLDS(gb, lb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IPX_MFMA1(1, 2); IPX_MFMA1(1, 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IPX_GLDS(gb + 8192, lb + 8192);
+                } else {
+                    IPX_MFMA1(0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IPX_GLDS(ga, la);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IPX_MFMA1(1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IPX_GLDS(ga + 8192, la + 8192);
+                    IPX_GLDS(gb, lb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#undef IPX_MFMA1
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[i]), as_bf16x8(b1[j]), acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < HNBUF; ++i) cur[i] = cur[i + 1];
-            cur[HNBUF] = advance(cur[HNBUF]);
+            for (int i = 0; i < NBUF; ++i) cur[i] = cur[i + 1];
+            cur[NBUF] = advance(cur[NBUF]);
+            slot = nslot;
         }
 
         // ---- epilogue: threshold filter, rare append to the per-query queues ----
         ++tiles_done;
+#ifdef IPX_ABL_NO_EPILOGUE    // diagnostic build: the bare MFMA pipeline (results are meaningless)
+        {
+            float m = 0.f;
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < QW; ++j) for (int r = 0; r < 16; ++r) m += acc[i][j][r];
+            if (m == 12345.678f) *p.err = 2;
+            continue;
+        }
+#endif
+        uint64_t tr_e0 = 0;
+        if (p.trace) tr_e0 = __builtin_readcyclecounter();
         const int docbase = t * HBD + wd * 64 + 4 * h;
         bool episode = lds_read_i32_nodma(&flags[(tiles_done + 1) & 1]) != 0;
         int* myflag = &flags[tiles_done & 1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ql = wq * 128 + j * 32 + l31;
+        for (int j = 0; j < QW; ++j) {
+            const int ql = wq * (32 * QW) + j * 32 + l31;
             const float tau = lds_read_f32_nodma(&taus[ql]);
             float m = acc[0][j][0];
 #pragma unroll
@@ -309,39 +390,59 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
                                 if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
                                 else *p.err = 1;
                                 if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
+                                ++tr_appends;
                             }
                         }
                     }
             }
         }
+        uint64_t tr_e1 = 0;
+        if (p.trace) { tr_e1 = __builtin_readcyclecounter(); tr_epi += tr_e1 - tr_e0; }
         episode = episode || is_pow4(tiles_done);
         if (episode) {
+            ++tr_episodes;
             // the sort scratch aliases the stage ring: let every copy land, sort, fetch the
-            // HNBUF stages again (cur[0]'s set-0 operands are already in registers)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                         : "+v"(a0[0]), "+v"(a0[1]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]) :: "memory");
+            // NBUF stages again (cur[0]'s set-0 operands are already in registers)
+            wait_set<QW, 0>(a0, b0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid < 2) flags[tid] = 0;
             if (wave < nsortwaves)
-                for (int ql = wave; ql < BQ; ql += nsortwaves)
+                for (int ql = wave; ql < BQ_; ql += nsortwaves)
                     compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, false, 0, 0,
                                   mypub ? mypub + ql : nullptr);
             __syncthreads();
-            if (tid < BQ) poll_union_threshold(p, taus, qb, tid);
+            if (tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
 #pragma unroll
-            for (int i = 0; i < HNBUF; ++i)
-                issue_stage_bf16(p, smem + ((g + i) & (HNBUF - 1)) * HSTAGE, cur[i].t, qb, cur[i].ks, wave, lane);
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HLOADS * (HNBUF - 1)) : "memory");
+            for (int i = 0; i < NBUF; ++i) {
+                const int sl = slot + i < NBUF ? slot + i : slot + i - NBUF;
+                issue_stage_bf16<QW>(p, smem + sl * STAGE, cur[i].t, qb, cur[i].ks, wave, lane);
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 1)) : "memory");
             __syncthreads();
+            if (p.trace) tr_sort += __builtin_readcyclecounter() - tr_e1;
         } else if ((tiles_done & 1) == 0 && is_pow4(tiles_done >> 1)) {
-            if (tid < BQ) poll_union_threshold(p, taus, qb, tid);
+            if (tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
+        }
+    }
+    if (p.trace) {
+        // [gridDim.x][4]: total cycles, filter cycles, compaction cycles (wave 0), appends (all lanes) << 16 | episodes
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tr_appends += __shfl_xor(tr_appends, off);
+        if (lane == 0) atomicAdd((unsigned long long*)(p.trace + (size_t)blockIdx.x * 4 + 3), ((unsigned long long)tr_appends << 16));
+        if (tid == 0) {
+            uint64_t* tr = p.trace + (size_t)blockIdx.x * 4;
+            tr[0] = __builtin_readcyclecounter() - tr_begin;
+            tr[1] = tr_epi;
+            tr[2] = tr_sort;
+            atomicAdd((unsigned long long*)(tr + 3), (unsigned long long)tr_episodes);
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (wave < nsortwaves)
-        for (int ql = wave; ql < BQ; ql += nsortwaves) {
-            const int64_t qglobal = (int64_t)qb * BQ + ql;
+        for (int ql = wave; ql < BQ_; ql += nsortwaves) {
+            const int64_t qglobal = (int64_t)qb * BQ_ + ql;
             if (qglobal < p.nq)
                 compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, true, qglobal, split, nullptr);
         }

@@ -596,8 +596,9 @@ __device__ __forceinline__ void wg_cmpx(uint32_t* os, int64_t* id, int lo, int h
 __global__ void __launch_bounds__(256)
 merge_topk_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, int S, int64_t nq,
                   int k_in, int k_out, int P, int lists_sorted, int64_t shard_stride, int64_t query_stride,
-                  float* __restrict__ outD, int64_t* __restrict__ outI) {
+                  float* __restrict__ outD, int64_t* __restrict__ outI, const int* __restrict__ only_flagged) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (only_flagged && !only_flagged[blockIdx.x]) return;   // merge_pool_kernel already served this query
     int64_t* rid = (int64_t*)smem;          // [P]
     int64_t* lid = rid + P;                 // [P]
     uint32_t* ros = (uint32_t*)(lid + P);   // [P]
@@ -650,6 +651,80 @@ merge_topk_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, in
         const bool empty = (i >= P) || ros[i] == 0;
         outD[q * k_out + i] = empty ? -FLT_MAX : f32_unordered(ros[i]);
         outI[q * k_out + i] = empty ? -1 : rid[i];
+    }
+}
+
+// Merge of S SORTED lists per query, S large (the scan's per-split lists when few queries spread
+// over every CU: S = 256 lists for a batch of <= 64 queries). Folding them one by one costs S
+// dependent merge rounds; this kernel cuts first: with r = ceil(k_out / S), every list holds r
+// entries at or above its own r-th entry, so v = the smallest of those r-th entries has at least
+// S*r >= k_out entries at or above it — nothing below v can be in the result. One thread per list
+// walks its head while entries are >= v into an LDS pool (lists are sorted: it stops at the first
+// smaller entry), the pool is sorted once, order (score desc, id asc). A pool overflow (masses of
+// ties) sets todo[q] = 1 and merge_topk_kernel folds that query the slow way.
+constexpr int MERGE_POOL = 4096;
+
+__global__ void __launch_bounds__(256)
+merge_pool_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, int S, int k_in, int k_out,
+                  int64_t shard_stride, int64_t query_stride, float* __restrict__ outD, int64_t* __restrict__ outI,
+                  int* __restrict__ todo) {
+    __shared__ int64_t pid[MERGE_POOL];
+    __shared__ uint32_t pos_[MERGE_POOL];
+    __shared__ uint32_t s_v;
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    const int r = (k_out + S - 1) / S;
+    if (tid == 0) { s_v = 0xffffffffu; s_n = 0; }
+    __syncthreads();
+    // v: the smallest r-th entry over the lists (0 = some list has fewer than r entries: no cut)
+    uint32_t mine = 0xffffffffu;
+    for (int s = tid; s < S; s += 256) {
+        uint32_t o = 0;
+        if (r <= k_in) {
+            const float sc = D[s * shard_stride + q * query_stride + (r - 1)];
+            if (sc > -FLT_MAX) o = f32_ordered(sc);
+        }
+        mine = o < mine ? o : mine;
+    }
+    atomicMin(&s_v, mine);
+    __syncthreads();
+    const uint32_t v = s_v;
+    for (int s = tid; s < S; s += 256) {
+        const float* d = D + s * shard_stride + q * query_stride;
+        const int64_t* ids = I + s * shard_stride + q * query_stride;
+        for (int i = 0; i < k_in; ++i) {
+            const float sc = d[i];
+            if (!(sc > -FLT_MAX)) break;              // empty slots (and NaN) end a list
+            const uint32_t o = f32_ordered(sc);
+            if (o < v) break;
+            const int at = atomicAdd(&s_n, 1);
+            if (at < MERGE_POOL) { pos_[at] = o; pid[at] = ids[i]; }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n > MERGE_POOL) {
+        if (tid == 0) todo[q] = 1;
+        return;
+    }
+    if (tid == 0) todo[q] = 0;
+    int P = 2;
+    while (P < n) P <<= 1;
+    for (int i = n + tid; i < P; i += 256) { pos_[i] = 0; pid[i] = INT64_MAX; }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (P >> 1); i += 256) {
+                const int lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1));
+                wg_cmpx(pos_, pid, lo, lo + stride, (lo & size) == 0);
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < k_out; i += 256) {
+        const bool empty = i >= n || pos_[i] == 0;
+        outD[q * k_out + i] = empty ? -FLT_MAX : f32_unordered(pos_[i]);
+        outI[q * k_out + i] = empty ? -1 : pid[i];
     }
 }
 

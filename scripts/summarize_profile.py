@@ -1,6 +1,7 @@
 """Condense a gpurun_out/prof_<tag>/ directory (scripts/profile_bench.sh) into profiles/<name>/."""
 import collections, csv, glob, json, os, shutil, sys
 tag, name = sys.argv[1], sys.argv[2]
+kern = sys.argv[3] if len(sys.argv) > 3 else 'scan_f32'
 src, dst = f'gpurun_out/prof_{tag}', f'profiles/{name}'
 os.makedirs(dst, exist_ok=True)
 shutil.copy(glob.glob(f'{src}/stats/vm/*kernel_stats.csv')[0], f'{dst}/kernel_stats.csv')
@@ -11,7 +12,7 @@ for t in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if 'scan_f32' in r['Kernel_Name']:
+        if kern in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
             out['dispatch'] = {k: r[k] for k in ('Grid_Size', 'Workgroup_Size', 'LDS_Block_Size', 'VGPR_Count', 'SGPR_Count')}
     out[t] = {k: sum(v) / len(v) for k, v in agg.items()}
@@ -21,5 +22,5 @@ if f is not None and w is not None:
     # the bytes of a wide (16 B/lane, LDS-DMA included) streaming read -> doubled; WRITE_SIZE exact.
     out['traffic_bytes_per_launch'] = f * 1024 * 2 + w * 1024
     out['traffic_note'] = 'memory-side (L2 fabric) bytes: FETCH_SIZE*1024*2 + WRITE_SIZE*1024; Infinity-Cache hits are included'
-json.dump(out, open(f'{dst}/scan_f32_pmc.json', 'w'), indent=1)
+json.dump(out, open(f'{dst}/{kern}_pmc.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
