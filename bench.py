@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: BF16 dense ~2.5 PF
+PEAK_HBM_GBS = 8000.0             # same guide: HBM3E 8 TB/s peak (about 6.3 TB/s achievable)
 BLOCK_ROWS = 200_000              # synthetic corpus is generated in blocks, seed = 1234 + block
 
 
@@ -66,9 +67,12 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-splits", type=int, default=0, help="diagnostic: cap the corpus splits per query block")
-    ap.add_argument("--storage", choices=["f32", "bf16scan", "bf16"], default="f32",
-                    help="f32: fp32 MFMA scan (headline); bf16scan: bf16 MFMA scan + exact fp32 rescoring "
-                         "(bit-identical results); bf16: bf16 rows only")
+    ap.add_argument("--storage", choices=["f32", "bf16scan", "bf16"], default="bf16scan",
+                    help="what the index keeps: f32 rows; f32 rows + a bf16 copy (default: serves the fp32 headline "
+                         "scan and the bf16 extras from one index); bf16 rows only")
+    ap.add_argument("--headline", choices=["f32", "bf16scan"], default="f32",
+                    help="which scan the timed K steps use on a bf16scan index (results are bit-identical)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bf16-scan and small-batch measurements")
     args = ap.parse_args()
 
     import numpy as np
@@ -120,51 +124,96 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        index.search(Q, k)
-    barrier()
-    scan_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        D, I = index.search(Q, k)
-        # HIP-event time of the scan kernel of this step (events sit on the launch stream;
-        # reading them waits for the kernel, which the step's result needs anyway)
-        scan_ms.append(ix.last_timing()["scan_ms"])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ix.check()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(queries, steps, warmup):
+        """W untimed + K timed searches; returns (max-over-ranks wall seconds, scan ms list, D, I)."""
+        for _ in range(warmup):
+            index.search(queries, k)
+        barrier()
+        scans = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            D, I = index.search(queries, k)
+            # HIP-event time of the scan kernel of this step (events sit on the launch stream;
+            # reading them waits for the kernel, which the step's result needs anyway)
+            scans.append(ix.last_timing()["scan_ms"])
+        barrier()
+        el = time.perf_counter() - t0
+        ix.check()
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, scans, D, I
+
+    # ---- headline: the metric's workload, timed exactly K steps ----
+    if args.storage == "bf16scan" and args.headline == "f32":
+        ix.set_param("f32_scan", 1)
+    elapsed, scan_ms, D, I = timed(Q, args.steps, args.warmup)
     ms_per_step = elapsed * 1e3 / args.steps
     assert int(I.min()) >= 0 and int(I.max()) < n and bool((D[:, :-1] >= D[:, 1:]).all())
+    geo, bf, tm = ix.last_geometry(), ix.last_bf16_stats(), ix.last_timing()
+    is_bf16 = bf["candidates"] > 0
+
+    # ---- extras (not the headline): the bf16 scan on the same index, and small batches ----
+    extra = {}
+    if args.storage == "bf16scan" and args.headline == "f32" and not args.no_extras:
+        ix.set_param("f32_scan", 0)
+        el2, sc2, D2, I2 = timed(Q, args.steps, 1)
+        bf2, tm2, geo2 = ix.last_bf16_stats(), ix.last_timing(), ix.last_geometry()
+        same = bool(torch.equal(I, I2)) and bool(torch.equal(D.view(torch.int32), D2.view(torch.int32)))
+        sc2a = sum(sc2) / len(sc2)
+        extra["bf16scan"] = {
+            "what": "same index, same queries: bf16 MFMA scan + exact fp32 rescoring; results compared bitwise with the headline run",
+            "bit_identical_to_f32_scan": same, "queries_per_s": nq / (el2 / args.steps), "ms_per_step": el2 * 1e3 / args.steps,
+            "scan_ms": sc2a, "merge_ms": round(tm2["merge_ms"], 3), "rescore_ms": round(bf2["rescore_ms"], 3),
+            "candidates": bf2["candidates"], "repeated_queries": bf2["fallback_queries"],
+            "workgroups": geo2["workgroups"], "splits": geo2["splits"],
+            "roofline": {"bound": "mfma", "achieved": 2.0 * nq * (hi - lo) * d / (sc2a * 1e-3) / 1e12,
+                         "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": 2.0 * nq * (hi - lo) * d / (sc2a * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                         "kernel": "scan_bf16_kernel<4>"}}
+        small = []
+        for bnq in (1, 16, 64):
+            el3, sc3, _, _ = timed(Q[:bnq].contiguous(), 20, 3)
+            sc3a = sum(sc3) / len(sc3)
+            bytes_scan = (hi - lo) * d * 2
+            small.append({"queries": bnq, "ms_per_search": el3 * 1e3 / 20, "queries_per_s": bnq / (el3 / 20),
+                          "scan_ms": sc3a, "corpus_bytes_streamed": bytes_scan,
+                          "roofline": {"bound": "hbm", "achieved": bytes_scan / (sc3a * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                       "unit": "GB/s", "frac": bytes_scan / (sc3a * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                       "kernel": "scan_bf16_kernel<1>"}})
+        extra["small_batch_bf16_copy"] = small
 
     if rank == 0:
         scan_avg = sum(scan_ms) / len(scan_ms)
         flops_launch = 2.0 * nq * (hi - lo) * d                      # algorithmic flops of one scan launch
         achieved = flops_launch / (scan_avg * 1e-3) / 1e12
-        geo = ix.last_geometry()
-        bf = ix.last_bf16_stats()
-        is_bf16 = bf["candidates"] > 0
         peak = PEAK_BF16_MFMA_TFLOPS if is_bf16 else PEAK_F32_MFMA_TFLOPS
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "latest_scan_f32_pmc.json")
+        if not is_bf16 and (n, nq, world) == (8_800_000, 6980, 1) and os.path.exists(prof):
+            # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command
+            # (FETCH_SIZE*1024*2 + WRITE_SIZE*1024, MI355X_MICROARCH.md §HBM); not collectable live
+            with open(prof) as f:
+                traffic = json.load(f).get("traffic_bytes_per_launch")
         out = {
             "metric": "QPS exact top-100 IP search, 8.8M×768 corpus @1/8 GPUs; % roofline",
             "value": nq / (ms_per_step * 1e-3),
             "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16 scan + f32 rescoring" if is_bf16 else "f32", "data": "synthetic: torch.randn on device, corpus seed 1234+block, query seed 4321",
+            "dtype": "bf16 scan + f32 rescoring" if is_bf16 else "f32",
+            "data": "synthetic: torch.randn on device, corpus seed 1234+block, query seed 4321",
             "config": {"workload": f"{n}x{d} fp32 corpus, {nq} queries, top-{k} (BASELINE.json configs[2] corpus, "
                                    f"headline depth 100)", "rows": n, "dim": d, "queries": nq, "k": k,
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
                        "workgroups": geo["workgroups"], "splits": geo["splits"], "queue_cap": geo["queue_cap"],
-                       "index_build_s": round(t_build, 2), "storage": args.storage,
-                       "bf16_candidates": bf["candidates"], "fallback_queries": bf["fallback_queries"],
-                       "rescore_ms": round(bf["rescore_ms"], 3), "merge_ms": round(ix.last_timing()["merge_ms"], 3)},
+                       "index_build_s": round(t_build, 2), "storage": args.storage, "headline_scan": "bf16" if is_bf16 else "f32",
+                       "bf16_candidates": bf["candidates"], "repeated_queries": bf["fallback_queries"],
+                       "rescore_ms": round(bf["rescore_ms"], 3), "merge_ms": round(tm["merge_ms"], 3)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
-                         "kernel": "scan_bf16_kernel" if is_bf16 else "scan_f32_kernel", "kernel_ms": scan_avg,
+                         "frac": achieved / peak, "traffic": traffic,
+                         "kernel": "scan_bf16_kernel<4>" if is_bf16 else "scan_f32_kernel", "kernel_ms": scan_avg,
                          "flops_per_launch": flops_launch},
         }
         if sample is not None and world == 1:
@@ -172,6 +221,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(Xs, Q.cpu().numpy(), k, n)
         elif world == 1:
             out["cpu_baseline"] = None
+        if extra:
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
