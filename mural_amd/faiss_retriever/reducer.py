@@ -45,9 +45,14 @@ def _pad_to(D, I, k):
 
 def combine_faiss_results(results: Iterable[Tuple[ndarray, ndarray]]):
     """reducer.py:10-20: global top-k over the shards' (scores, ids), k and the query count
-    taken from the first shard; ids are coerced to int64 (so string ids must be
-    integer-parsable, docs/retrieval.md:54). Returns (scores f32 [nq,k] descending,
-    ids int64 [nq,k]); unfilled slots are (-FLT_MAX, -1)."""
+    taken from the first shard. Returns (scores f32 [nq,k] descending, ids [nq,k]); unfilled
+    slots are (-FLT_MAX, -1).
+
+    Ids are coerced to int64 as in the reference (docs/retrieval.md:54: "reducer requires doc/query
+    id being integer"). Beyond the reference: id arrays that are NOT integer-parsable (MA-Amazon
+    product ids are ASIN strings, data.py:1362) are accepted too — every distinct string gets an
+    integer code in first-seen order for the merge, and the result carries the strings back as a
+    '<U' array (ties between equal scores then break in first-seen order)."""
     device = int(os.environ.get("IPX_DEVICE", "0"))
     nq = k = None
     run_D = run_I = None
@@ -68,13 +73,38 @@ def combine_faiss_results(results: Iterable[Tuple[ndarray, ndarray]]):
         run_D, run_I = _merge(bd, bi, k, device)
         pend_D, pend_I = [], []
 
+    codes = None            # str -> code, once a shard with non-integer ids has been seen
+    names = []
+
+    def intern(ids):
+        nonlocal codes
+        if codes is None:
+            codes = {}
+        uniq, inv = np.unique(np.asarray(ids).astype(str), return_inverse=True)
+        table = np.empty(len(uniq), dtype=np.int64)
+        for j, name in enumerate(uniq.tolist()):
+            c = codes.get(name)
+            if c is None:
+                c = codes[name] = len(names)
+                names.append(name)
+            table[j] = c
+        return table[inv].reshape(np.shape(ids))
+
     for scores, indices in results:
         if nq is None:
             print(f'Initializing Heap. Assuming {scores.shape[0]} queries.')
             nq, k = scores.shape[0], scores.shape[1]
         n, kd = scores.shape
         scores = np.ascontiguousarray(scores, dtype='float32')
-        indices = np.ascontiguousarray(indices, dtype='int64')
+        if codes is None:
+            try:
+                indices = np.ascontiguousarray(indices, dtype='int64')
+            except ValueError:
+                if run_D is not None or pend_D:
+                    raise           # integer shards were merged already: mixing the two id kinds is an error
+                indices = intern(indices)
+        else:
+            indices = intern(indices)
         assert indices.shape == (n, kd)
         assert n == nq
         pend_D.append(scores), pend_I.append(indices)
@@ -84,6 +114,9 @@ def combine_faiss_results(results: Iterable[Tuple[ndarray, ndarray]]):
     # the reference fails on an empty iterable (rh is None -> AttributeError on finalize)
     if run_D is None:
         raise AttributeError("'NoneType' object has no attribute 'finalize'")
+    if codes is not None:
+        table = np.array(names + ['-1'])        # code -1 (an unfilled slot) -> '-1'
+        run_I = table[run_I]
     return run_D, run_I
 
 
