@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -75,6 +76,9 @@ struct ipx_index {
     uint16_t* Xh = nullptr;  // packed bf16 corpus (storage 1, 2)
     DevBuf Qp, cand, partD, partI, err, stageIn, stageQ, stageW, outD, outI, trace, pub;
     DevBuf maxsq, qfused, candD, candI, flags, sel, qsel, selD, selI;
+    void* pinned = nullptr;          // host staging of ipx_add (two slices)
+    size_t pinned_bytes = 0;
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
     bool trace_on = false;
     bool timing = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -652,6 +656,9 @@ int ipx_destroy(ipx_index* ix) {
         b->release();
     for (auto& e : ix->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : ix->ev_stage)
+        if (e) (void)hipEventDestroy(e);
+    if (ix->pinned) (void)hipHostFree(ix->pinned);
     delete ix;
     return 0;
 }
@@ -690,16 +697,48 @@ int ipx_add(ipx_index* ix, const void* rows, int64_t n, int dtype, int on_device
             if (int rc = add_device_rows(ix, (const char*)rows + r0 * row_bytes, dtype, m, ix->ntotal + r0, st)) return rc;
         }
     } else {
-        // host rows: stage through a bounded device buffer (256 MiB), one copy per slice
-        const int64_t slice = std::max<int64_t>(1, (int64_t)(256ull << 20) / (int64_t)row_bytes);
-        if (int rc = ix->stageIn.ensure((size_t)std::min(slice, n) * row_bytes)) return rc;
-        for (int64_t r0 = 0; r0 < n; r0 += slice) {
-            const int64_t m = std::min(slice, n - r0);
-            IPX_HIP(hipMemcpyAsync(ix->stageIn.p, (const char*)rows + r0 * row_bytes, (size_t)m * row_bytes,
-                                   hipMemcpyHostToDevice, st));
-            if (int rc = add_device_rows(ix, ix->stageIn.p, dtype, m, ix->ntotal + r0, st)) return rc;
-            IPX_HIP(hipStreamSynchronize(st));   // the staging buffer is reused by the next slice
+        // host rows (pageable memory, e.g. an unpickled ndarray): two pinned 64-MiB buffers and two
+        // device staging buffers; while slice i travels over PCIe and is packed, host threads copy
+        // slice i+1 into the other pinned buffer. The caller's array is read once, never pinned.
+        const int64_t slice = std::max<int64_t>(1, (int64_t)(64ull << 20) / (int64_t)row_bytes);
+        const size_t slice_bytes = (size_t)std::min(slice, n) * row_bytes;
+        if (int rc = ix->stageIn.ensure(2 * slice_bytes)) return rc;
+        if (!ix->pinned || ix->pinned_bytes < 2 * slice_bytes) {
+            if (ix->pinned) (void)hipHostFree(ix->pinned);
+            ix->pinned = nullptr;
+            ix->pinned_bytes = 0;
+            hipError_t e = hipHostMalloc(&ix->pinned, 2 * slice_bytes, hipHostMallocDefault);
+            if (e != hipSuccess) { ix->pinned = nullptr; return fail(IPX_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+            ix->pinned_bytes = 2 * slice_bytes;
         }
+        for (auto& e : ix->ev_stage)
+            if (!e) IPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        const int nthreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+        int64_t i = 0;
+        for (int64_t r0 = 0; r0 < n; r0 += slice, ++i) {
+            const int64_t m = std::min(slice, n - r0);
+            const int b = (int)(i & 1);
+            char* pin = (char*)ix->pinned + (size_t)b * slice_bytes;
+            char* dev = (char*)ix->stageIn.p + (size_t)b * slice_bytes;
+            if (i >= 2) IPX_HIP(hipEventSynchronize(ix->ev_stage[b]));   // the copy out of this pinned buffer is done
+            const char* src = (const char*)rows + r0 * row_bytes;
+            const size_t bytes = (size_t)m * row_bytes;
+            if (nthreads == 1 || bytes < (8u << 20)) {
+                memcpy(pin, src, bytes);
+            } else {
+                std::vector<std::thread> th;
+                const size_t per = (bytes / nthreads + 4095) & ~(size_t)4095;
+                for (int t = 0; t < nthreads; ++t) {
+                    const size_t lo = std::min(bytes, (size_t)t * per), hi = std::min(bytes, lo + per);
+                    if (hi > lo) th.emplace_back([=] { memcpy(pin + lo, src + lo, hi - lo); });
+                }
+                for (auto& t : th) t.join();
+            }
+            IPX_HIP(hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, st));
+            IPX_HIP(hipEventRecord(ix->ev_stage[b], st));
+            if (int rc = add_device_rows(ix, dev, dtype, m, ix->ntotal + r0, st)) return rc;
+        }
+        IPX_HIP(hipStreamSynchronize(st));   // host-pointer calls are synchronous
     }
     ix->ntotal += n;
     return 0;

@@ -105,7 +105,10 @@ def pickle_load(path):
         payload = pickle.load(f)
     if len(payload) not in (2, 4):
         raise UnboundLocalError("local variable 'reps' referenced before assignment")
-    return np.array(payload[0]), payload[1]
+    # the reference copies here (np.array); an unpickled ndarray is already private to this call,
+    # so it is handed on as is — a 27 GB corpus shard is not duplicated in host memory
+    reps = payload[0]
+    return (reps if isinstance(reps, np.ndarray) else np.array(reps)), payload[1]
 
 
 def pickle_save(obj, path):
@@ -137,8 +140,9 @@ def _load_index(pattern):
         shards = tqdm(shards, desc='Loading shards into index', total=len(index_files))
     look_up = []
     for p_reps, p_lookup in shards:
-        # float16 shards are widened to float32 on the device (same values as .astype)
-        retriever.add(p_reps if p_reps.dtype == np.float16 else p_reps.astype('float32'))
+        # float16 shards are widened to float32 on the device (same values as .astype);
+        # float32 shards go down as they are (no host copy)
+        retriever.add(p_reps if p_reps.dtype == np.float16 else p_reps.astype('float32', copy=False))
         look_up += p_lookup
     return retriever, look_up
 

@@ -43,16 +43,18 @@ def _pad_to(D, I, k):
     return pd, pi
 
 
-def combine_faiss_results(results: Iterable[Tuple[ndarray, ndarray]]):
+def combine_faiss_results(results: Iterable[Tuple[ndarray, ndarray]], string_ids: bool = False):
     """reducer.py:10-20: global top-k over the shards' (scores, ids), k and the query count
     taken from the first shard. Returns (scores f32 [nq,k] descending, ids [nq,k]); unfilled
     slots are (-FLT_MAX, -1).
 
     Ids are coerced to int64 as in the reference (docs/retrieval.md:54: "reducer requires doc/query
-    id being integer"). Beyond the reference: id arrays that are NOT integer-parsable (MA-Amazon
-    product ids are ASIN strings, data.py:1362) are accepted too — every distinct string gets an
-    integer code in first-seen order for the merge, and the result carries the strings back as a
-    '<U' array (ties between equal scores then break in first-seen order)."""
+    id being integer"; anything else is a ValueError). Beyond the reference, opt-in with
+    string_ids=True (CLI: --string_ids, or IPX_REDUCER_STRING_IDS=1): id arrays that are not
+    integer-parsable (MA-Amazon product ids are ASIN strings, data.py:1362) are accepted — every
+    distinct string gets an integer code for the merge and the result carries the strings back
+    as a '<U' array (ties between equal scores break in code order: first shard first)."""
+    string_ids = string_ids or os.environ.get("IPX_REDUCER_STRING_IDS", "0") not in ("", "0")
     device = int(os.environ.get("IPX_DEVICE", "0"))
     nq = k = None
     run_D = run_I = None
@@ -100,7 +102,7 @@ def combine_faiss_results(results: Iterable[Tuple[ndarray, ndarray]]):
             try:
                 indices = np.ascontiguousarray(indices, dtype='int64')
             except ValueError:
-                if run_D is not None or pend_D:
+                if not string_ids or run_D is not None or pend_D:
                     raise           # integer shards were merged already: mixing the two id kinds is an error
                 indices = intern(indices)
         else:
@@ -124,10 +126,12 @@ def main():
     parser = ArgumentParser()
     for flag in ('--score_dir', '--query', '--save_ranking_to'):
         parser.add_argument(flag, required=True)
+    parser.add_argument('--string_ids', action='store_true',
+                        help='not in the reference: accept doc ids that are not integers')
     args = parser.parse_args()
 
     partitions = glob.glob(f'{args.score_dir}/*')
-    corpus_scores, corpus_indices = combine_faiss_results(map(pickle_load, tqdm(partitions)))
+    corpus_scores, corpus_indices = combine_faiss_results(map(pickle_load, tqdm(partitions)), string_ids=args.string_ids)
 
     _, q_lookup = pickle_load(args.query)
     write_ranking(corpus_indices, corpus_scores, q_lookup, args.save_ranking_to)

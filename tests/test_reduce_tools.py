@@ -64,7 +64,9 @@ def test_combine_faiss_results_with_string_ids():
         D = -np.sort(-rng.standard_normal((nq, k)).astype(np.float32), axis=1)
         I = np.array([[f"B00{s}{q:02d}X{j}" for j in range(k)] for q in range(nq)])
         shards.append((D, I))
-    oD, oI = combine_faiss_results(iter(shards))
+    with pytest.raises(ValueError):                 # the reference's behaviour stays the default
+        combine_faiss_results(iter(shards))
+    oD, oI = combine_faiss_results(iter(shards), string_ids=True)
     assert oI.dtype.kind == "U" and oD.dtype == np.float32
     allD = np.concatenate([d for d, _ in shards], axis=1)
     allI = np.concatenate([i for _, i in shards], axis=1)
@@ -73,5 +75,5 @@ def test_combine_faiss_results_with_string_ids():
     assert np.array_equal(oI, np.take_along_axis(allI, order, axis=1))
     # integer-parsable strings keep the reference behaviour: int64 ids
     ints = [(d, np.char.add("1", np.arange(k).astype(str))[None, :].repeat(nq, 0)) for d, _ in shards[:2]]
-    _, iI = combine_faiss_results(iter(ints))
+    _, iI = combine_faiss_results(iter(ints), string_ids=True)
     assert iI.dtype == np.int64
