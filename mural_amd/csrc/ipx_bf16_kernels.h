@@ -270,7 +270,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
 
     int slot = 0, tiles_done = 0;
     // optional trace (ipx_set_param "trace"): wave 0's view of where the time goes
-    uint64_t tr_epi = 0, tr_sort = 0, tr_begin = 0;
+    uint64_t tr_epi = 0, tr_sort = 0, tr_begin = 0, tr_w1 = 0, tr_own = 0, tr_w2 = 0;
     uint32_t tr_appends = 0, tr_episodes = 0;
     if (p.trace) tr_begin = __builtin_readcyclecounter();
     while (cur[0].ok) {
@@ -406,12 +406,16 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             wait_set<QW, 0>(a0, b0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            uint64_t tr_a = 0, tr_b = 0;
+            if (p.trace) { tr_a = __builtin_readcyclecounter(); tr_w1 += tr_a - tr_e1; }
             if (tid < 2) flags[tid] = 0;
             if (wave < nsortwaves)
                 for (int ql = wave; ql < BQ_; ql += nsortwaves)
-                    compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, false, 0, 0,
-                                  mypub ? mypub + ql : nullptr);
+                    compact_query_select(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
+                                         mypub ? mypub + ql : nullptr);
+            if (p.trace) { tr_b = __builtin_readcyclecounter(); tr_own += tr_b - tr_a; }
             __syncthreads();
+            if (p.trace) tr_w2 += __builtin_readcyclecounter() - tr_b;
             if (tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
 #pragma unroll
             for (int i = 0; i < NBUF; ++i) {
@@ -435,6 +439,8 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             tr[0] = __builtin_readcyclecounter() - tr_begin;
             tr[1] = tr_epi;
             tr[2] = tr_sort;
+            uint64_t* tx = p.trace + (size_t)gridDim.x * 4 + (size_t)blockIdx.x * 4;   // episode split (wave 0)
+            tx[0] = tr_w1; tx[1] = tr_own; tx[2] = tr_w2; tx[3] = 0;
             atomicAdd((unsigned long long*)(tr + 3), (unsigned long long)tr_episodes);
         }
     }

@@ -248,6 +248,108 @@ __device__ __forceinline__ void compact_query(const ScanParams& p, uint64_t* scr
     wave_lds_sync();
 }
 
+// Non-final compaction by SELECTION instead of sorting (used by the bf16 scans, whose tiles are
+// 8x shorter than the fp32 kernel's, so episodes weigh 8x more): one wave keeps query `ql`'s best
+// k keys of the n in its queue (in any order), raises the threshold to the k-th best score and
+// publishes the r-th best. The keys' high words (ordered scores) go to the wave's LDS scratch;
+// the k-th largest is found bit by bit from the top — 32 steps of "how many are >= candidate",
+// counted with wave ballots (a scalar count, no cross-lane reduction); ties at the cut are
+// resolved the same way on the low words (row ids); the survivors move to the front of the queue
+// in place (every position written lies below every position still to be read). All memory
+// traffic goes in batches of 8 independent accesses per lane: the cost is latency, not volume.
+__device__ __forceinline__ uint32_t nth_largest_lds(const uint32_t* sh, int kpl8, int lane, int need) {
+    uint32_t t = 0;
+#pragma unroll 1
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t cand = t | (1u << b);
+        int cnt = 0;
+#pragma unroll 1
+        for (int j0 = 0; j0 < kpl8; j0 += 8) {
+            uint32_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = sh[lane + 64 * (j0 + u)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cnt += __popcll(__ballot(x[u] >= cand));
+        }
+        if (cnt >= need) t = cand;
+    }
+    return t;
+}
+
+__device__ __forceinline__ void compact_query_select(const ScanParams& p, uint64_t* scratch, int* cnts, float* taus,
+                                                     uint64_t* queue, int ql, int lane, uint32_t* pub_slot) {
+    const int n = cnts[ql];
+    const bool publish = pub_slot && n >= p.r;
+    if (n <= p.k && !publish) return;
+    const int kpl8 = (((n + 63) >> 6) + 7) & ~7;         // slots per lane, in batches of 8 (64 * kpl8 <= cap)
+    uint32_t* sh = (uint32_t*)scratch;                    // [64 * kpl8] high words; then [64 * kpl8] low words of tied keys
+    const uint32_t* q32 = (const uint32_t*)queue;
+#pragma unroll 1
+    for (int j0 = 0; j0 < kpl8; j0 += 8) {
+        uint32_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = lane + 64 * (j0 + u);
+            x[u] = q32[2 * (i < n ? i : n - 1) + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = lane + 64 * (j0 + u);
+            sh[i] = i < n ? x[u] : 0u;
+        }
+    }
+    wave_lds_sync();
+    if (publish) {
+        const uint32_t vr = nth_largest_lds(sh, kpl8, lane, p.r);
+        if (lane == 0) __hip_atomic_store(pub_slot, vr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (n <= p.k) return;
+    const uint32_t v = nth_largest_lds(sh, kpl8, lane, p.k);      // >= 1: empty slots (0) never pass
+    // ties at the cut: only the (k - #above) tied keys with the largest low words survive
+    int above = 0, tied = 0;
+#pragma unroll 1
+    for (int j = 0; j < kpl8; ++j) {
+        const uint32_t h = sh[lane + 64 * j];
+        above += __popcll(__ballot(h > v));
+        tied += __popcll(__ballot(h == v));
+    }
+    uint32_t lcut = 0;
+    if (tied > p.k - above) {
+        uint32_t* sl = sh + 64 * kpl8;
+#pragma unroll 1
+        for (int j = 0; j < kpl8; ++j) {
+            const int i = lane + 64 * j;
+            sl[i] = sh[i] == v ? q32[2 * i] : 0u;
+        }
+        wave_lds_sync();
+        lcut = nth_largest_lds(sl, kpl8, lane, p.k - above);
+    }
+    int base = 0;
+#pragma unroll 1
+    for (int j0 = 0; j0 < kpl8; j0 += 8) {
+        uint64_t key[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = lane + 64 * (j0 + u);
+            key[u] = queue[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = lane + 64 * (j0 + u);
+            const uint32_t h = (uint32_t)(key[u] >> 32);
+            const bool keep = i < n && (h > v || (h == v && (uint32_t)key[u] >= lcut));
+            const uint64_t mask = __ballot(keep);
+            if (keep) queue[base + __popcll(mask & ((1ull << lane) - 1))] = key[u];
+            base += __popcll(mask);
+        }
+    }
+    if (lane == 0) {
+        cnts[ql] = base;                          // == k
+        taus[ql] = fmaxf(taus[ql], f32_unordered(v));
+    }
+    wave_lds_sync();
+}
+
 // Union threshold. Every split publishes the score of its r-th best hit so far, r = ceil(k/S).
 // Taking the minimum v over the S splits of one query: each split holds >= r rows scoring >= v,
 // so >= S*r >= k rows of the index score >= v and the global k-th best score is >= v. A row

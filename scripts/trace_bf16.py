@@ -15,10 +15,17 @@ Q = torch.randn((nq, 768), generator=g, device=dev)
 ix.set_timing(True); ix.set_param("trace", 1)
 for it in range(2):
     ix.search_device(Q, 100); torch.cuda.synchronize()
-tr = ix.read_trace().astype(np.float64)
+import ctypes as C
+from mural_amd import _lib
+n = ix.last_geometry()["workgroups"]
+raw = np.zeros((2 * n, 4), dtype=np.uint64)
+_lib.check(_lib.lib().ipx_read_trace(ix._h, C.c_void_p(raw.ctypes.data), 2 * n))
+tr = raw[:n].astype(np.float64); ex = raw[n:].astype(np.float64)
 tot, epi, srt = tr[:, 0], tr[:, 1], tr[:, 2]
 app, eps = (tr[:, 3].astype(np.uint64) >> 16).astype(np.float64), (tr[:, 3].astype(np.uint64) & 0xffff).astype(np.float64)
 geo = ix.last_geometry(); tiles = (rows / 256) * np.ceil(nq / 256) / geo["workgroups"]
 print(f"scan {ix.last_timing()['scan_ms']:.2f} ms wgs {geo['workgroups']} S {geo['splits']} cap {geo['queue_cap']} tiles/wg {tiles:.0f}")
 print(f"per WG mean: total {tot.mean():.3e} ticks, filter {epi.mean()/tot.mean():.3f}, compaction {srt.mean()/tot.mean():.3f}, "
       f"appends {app.mean():.0f} ({app.mean()/tiles:.1f}/tile), episodes {eps.mean():.1f} (max {eps.max():.0f})")
+print(f"episode split (wave 0, share of total): wait for the other waves' filters {ex[:,0].mean()/tot.mean():.3f}, own compaction {ex[:,1].mean()/tot.mean():.3f}, "
+      f"wait for the other waves' compaction {ex[:,2].mean()/tot.mean():.3f}")
