@@ -111,7 +111,9 @@ int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in
  *                  2 bf16 rows only (rows given as bf16 are kept exactly, fp32 / f16 rows are
  *                    rounded to nearest even): bf16 scan, then exact fp32 scores of
  *                    <fp32 query, stored bf16 row>; half the HBM of storage 0.
- *   "bf16_candidates" : candidates per query the bf16 scan keeps (0 = automatic: 4k / 2k).
+ *   "bf16_candidates" : candidates per query the bf16 scan keeps (0 = automatic).
+ *   "query_parts": bf16 parts per query in the bf16 scan: 1 = bf16(q); 2 = hi + lo (16 bits of
+ *                  the query, twice the MFMA work, a far smaller margin); 0 = automatic.
  *   "f32_scan"   : 1 = storage 1 searches with the fp32 scan (A/B measurements on one index).
  *   "max_splits" : upper bound on the corpus splits per query block (0 = automatic).
  *   "trace"      : 1 = every scan workgroup records {start, end (100 MHz ticks), HW_ID,

@@ -88,6 +88,7 @@ struct ipx_index {
     int64_t last_fallback = 0;       // queries the last search repeated on the fp32 scan
     int max_splits = 0;      // 0 = automatic
     int force_kc = 0;        // 0 = automatic candidate count
+    int query_parts = 0;     // 0 = automatic; 1 / 2 bf16 parts per query in the bf16 scan
     bool no_small_batch = false;   // diagnostic: always use the 256-query bf16 scan variant
     bool force_f32_scan = false;   // storage 1: use the fp32 scan although a bf16 copy exists
     size_t tile_bytes() const { return (size_t)nks * ipx::STAGE_A_BYTES; }
@@ -149,13 +150,13 @@ int grow_corpus_h(ipx_index* ix, int64_t need_tiles, hipStream_t st) {
 }
 
 int launch_pack_bf16(const void* src, int dtype, int64_t n, int64_t n_pad, int d, uint16_t* dst, int64_t row0,
-                     int rows_per_tile, int nks_h, hipStream_t st) {
+                     int rows_per_tile, int nks_h, int parts, hipStream_t st) {
     const int64_t total = n_pad * nks_h * 4;
     if (total == 0) return 0;
     const int64_t blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return fail(IPX_ERR_ARG, "pack: too many rows in one call");
     hipLaunchKernelGGL(ipx::pack_rows_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dtype, n, n_pad, d,
-                       dst, row0, rows_per_tile, nks_h);
+                       dst, row0, rows_per_tile, nks_h, parts);
     IPX_HIP(hipGetLastError());
     return 0;
 }
@@ -177,7 +178,7 @@ int add_device_rows(ipx_index* ix, const void* rows, int dtype, int64_t m, int64
     if (ix->storage != 2)
         if (int rc = launch_pack(rows, dtype, m, m, ix->d, ix->Xp, row0, ipx::BD, ix->nks, nullptr, 0, 0, st)) return rc;
     if (ix->storage != 0) {
-        if (int rc = launch_pack_bf16(rows, dtype, m, m, ix->d, ix->Xh, row0, ipx::HBD, ix->nks_h, st)) return rc;
+        if (int rc = launch_pack_bf16(rows, dtype, m, m, ix->d, ix->Xh, row0, ipx::HBD, ix->nks_h, 1, st)) return rc;
         // the margin bound uses |x|_2 of the values the exact score is defined on: the fp32 rows
         // (storage 1) or the stored bf16 rows (storage 2; rounding can only matter upwards by 2^-8)
         const int blocks = (int)std::min<int64_t>((m + 3) / 4, 4096);
@@ -305,22 +306,26 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
 }
 
 // Error coefficient of the margin rule (rescore_kernel): |approx - exact| <= coef * |q| * max|x|.
-//   bf16 rounding (to nearest, unit roundoff u = 2^-9) of q, and of x unless the rows are stored
-//   bf16 and the exact score is defined on them: (1+u)^2 - 1 or u;
-//   fp32 accumulation of the exact chain: (d+1) * 2^-24; of the MFMA chain: 4x that, in case the
-//   matrix core's internal adds are not round-to-nearest; 0.2 % slack for the fp32 norms.
-float margin_coef(int d_pad, bool rows_exact_bf16) {
+//   rounding to bf16 (to nearest, unit roundoff u = 2^-9): of x, unless the rows are stored bf16
+//   and the exact score is defined on them; of q, u with one part, u^2 (+ slack: 2^-17) with the
+//   hi + lo split; cross terms included by multiplying out (1+ex)(1+eq) - 1;
+//   fp32 accumulation of the exact chain: (d+1) * 2^-24; of the MFMA chain (d products per part):
+//   4x that, in case the matrix core's internal adds are not round-to-nearest; 0.2 % slack for the
+//   fp32 norms.
+float margin_coef(int d_pad, bool rows_exact_bf16, int qparts) {
     const double u = 1.0 / 512.0;
-    const double round_err = rows_exact_bf16 ? u : (2.0 * u + u * u);
-    const double acc_err = 5.0 * (d_pad + 1) / 16777216.0;
+    const double ex = rows_exact_bf16 ? 0.0 : u;
+    const double eq = qparts == 2 ? 1.0 / 131072.0 : u;
+    const double round_err = (1.0 + ex) * (1.0 + eq) - 1.0;
+    const double acc_err = (1.0 + 4.0 * qparts) * (d_pad + 1) / 16777216.0;
     return (float)((round_err + acc_err) * 1.002);
 }
 
 // One bf16 pass over nq row-major fp32 queries (device): pack -> bf16 scan keeping kc candidates
 // -> merge -> exact rescoring into dD / dI. Synchronises the stream and returns in `flagged` the
 // queries whose candidate list could not be proven sufficient (their rows of dD / dI are not final).
-int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, float* dD, int64_t* dI, hipStream_t st,
-              bool primary, std::vector<int>& flagged) {
+int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qparts, float* dD, int64_t* dI,
+              hipStream_t st, bool primary, std::vector<int>& flagged) {
     const int d = ix->d, nks = ix->nks_h;
     const int64_t N = ix->ntotal;
     const size_t ncand = (size_t)nq * kc;
@@ -329,7 +334,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, float* 
     // up to 64 queries: the 64-query variant (a quarter of the MFMA work per corpus byte)
     const bool small = nq <= 64 && !ix->no_small_batch;
     const int bq = small ? 64 : 256;
-    const int stage_b = bq * 64;
+    const int stage_b = bq * 64 * qparts;
     const int nqb = (int)((nq + bq - 1) / bq);
     const int ntiles = (int)((N + ipx::HBD - 1) / ipx::HBD);
     hipDeviceProp_t prop;
@@ -343,7 +348,8 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, float* 
     const int G = nqb * S;
     // queue: kc survivors of a compaction + 2 tiles of appends before the next one runs + room to fill
     const int cap = next_pow2(kc + 2 * ipx::HBD + kc / 2);
-    const int ring = small ? ipx::HCfg<1>::RING : ipx::HCfg<4>::RING;
+    const int ring = small ? (qparts == 2 ? ipx::HCfg<1, 2>::RING : ipx::HCfg<1, 1>::RING)
+                           : (qparts == 2 ? ipx::HCfg<4, 2>::RING : ipx::HCfg<4, 1>::RING);
     const int nsortwaves = std::max(1, std::min(8, ring / (cap * 8)));
 
     if (int rc = ix->Qp.ensure((size_t)nqb * nks * stage_b)) return rc;
@@ -362,7 +368,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, float* 
     IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
 
     if (timing) IPX_HIP(hipEventRecord(ix->ev[0], st));
-    if (int rc = launch_pack_bf16(qf, IPX_F32, nq, (int64_t)nqb * bq, d, (uint16_t*)ix->Qp.p, 0, bq, nks, st)) return rc;
+    if (int rc = launch_pack_bf16(qf, IPX_F32, nq, (int64_t)nqb * bq, d, (uint16_t*)ix->Qp.p, 0, bq, nks, qparts, st)) return rc;
     if (timing) IPX_HIP(hipEventRecord(ix->ev[1], st));
 
     ipx::ScanParams p;
@@ -391,12 +397,12 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, float* 
     p.S = S;
     p.ntiles = ntiles;
     const int lds = std::max(ring, nsortwaves * cap * 8) + ipx::LDS_STATE_BYTES;
-    if (small) {
-        IPX_HIP(hipFuncSetAttribute((const void*)ipx::scan_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(ipx::scan_bf16_kernel<1>, dim3(G), dim3(ipx::HTHREADS), lds, st, p, nsortwaves);
-    } else {
-        IPX_HIP(hipFuncSetAttribute((const void*)ipx::scan_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(ipx::scan_bf16_kernel<4>, dim3(G), dim3(ipx::HTHREADS), lds, st, p, nsortwaves);
+    {
+        void (*kern)(const ipx::ScanParams, const int) =
+            small ? (qparts == 2 ? ipx::scan_bf16_kernel<1, 2> : ipx::scan_bf16_kernel<1, 1>)
+                  : (qparts == 2 ? ipx::scan_bf16_kernel<4, 2> : ipx::scan_bf16_kernel<4, 1>);
+        IPX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(kern, dim3(G), dim3(ipx::HTHREADS), lds, st, p, nsortwaves);
     }
     IPX_HIP(hipGetLastError());
     if (timing) IPX_HIP(hipEventRecord(ix->ev[2], st));
@@ -439,7 +445,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, float* 
     rp.outI = dI;
     rp.flags = (int*)ix->flags.p;
     rp.id_base = ix->id_base;
-    rp.coef = margin_coef(ix->nks_h * ipx::HBK, ix->storage == 2);
+    rp.coef = margin_coef(ix->nks_h * ipx::HBK, ix->storage == 2, qparts);
     rp.d = d;
     rp.k = k;
     rp.kc = kc;
@@ -502,8 +508,13 @@ int redo_queries(ipx_index* ix, const float* qf, const std::vector<int>& sel, in
 int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
                    float* dD, int64_t* dI, hipStream_t st) {
     const int d = ix->d;
-    // candidates per query: 4k (2k when only the query is rounded), within [256, IPX_MAX_K]
-    int kc = ix->force_kc > 0 ? ix->force_kc : std::max(256, (ix->storage == 2 ? 2 : 4) * k);
+    // One bf16 part per query and 4k candidates (2k when only the query is rounded) while that
+    // list stays short; deeper searches split the query into hi + lo parts — the margin then only
+    // carries the rows' rounding (none in storage 2) — and keep 2k (1.25k) candidates.
+    int qparts = ix->query_parts > 0 ? ix->query_parts : ((ix->storage == 2 ? 2 : 4) * k > 1024 ? 2 : 1);
+    int kc = ix->force_kc > 0 ? ix->force_kc
+             : qparts == 1 ? std::max(256, (ix->storage == 2 ? 2 : 4) * k)
+                           : std::max(256, ix->storage == 2 ? k + k / 4 : 2 * k);
     kc = std::min(std::max(kc, k), (int)IPX_MAX_K);
 
     const float* qf = dq;
@@ -516,12 +527,12 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
         qf = (const float*)ix->qfused.p;
     }
     std::vector<int> flagged;
-    if (int rc = bf16_pass(ix, qf, nq, k, kc, dD, dI, st, true, flagged)) return rc;
+    if (int rc = bf16_pass(ix, qf, nq, k, kc, qparts, dD, dI, st, true, flagged)) return rc;
     ix->last_fallback = (int64_t)flagged.size();
-    if (!flagged.empty() && kc < IPX_MAX_K) {
+    if (!flagged.empty() && (kc < IPX_MAX_K || qparts == 1)) {    // longest list, hi + lo query
         std::vector<int> still;
         int rc = redo_queries(ix, qf, flagged, k, dD, dI, st, [&](const float* q2, int64_t n2, float* D2, int64_t* I2) {
-            return bf16_pass(ix, q2, n2, k, IPX_MAX_K, D2, I2, st, false, still);
+            return bf16_pass(ix, q2, n2, k, IPX_MAX_K, 2, D2, I2, st, false, still);
         });
         if (rc) return rc;
         for (int& i : still) i = flagged[(size_t)i];
@@ -590,10 +601,9 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
     } else {
         if (int rc = ix->err.ensure(256)) return rc;
         IPX_HIP(hipMemsetAsync(ix->err.p, 0, 256, st));
-        // bf16 scan when the index keeps a bf16 copy; with fp32 rows at hand, depths whose
-        // 4k candidates exceed the list limit go straight to the fp32 scan
+        // bf16 scan whenever the index keeps a bf16 copy
         const bool bf16 = ix->storage == 2 ||
-                          (ix->storage == 1 && !ix->force_f32_scan && (4 * k <= IPX_MAX_K || ix->force_kc > 0));
+                          (ix->storage == 1 && !ix->force_f32_scan);
         int rc = bf16 ? scan_bf16_path(ix, dq, dw, A, logits, nq, k, dD, dI, st)
                       : scan_f32_path(ix, dq, dw, A, logits, nq, k, dD, dI, st, true);
         if (rc) return rc;
@@ -823,6 +833,11 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
     }
     if (!strcmp(name, "no_small_batch")) {
         ix->no_small_batch = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "query_parts")) {
+        if (value < 0 || value > 2) return fail(IPX_ERR_ARG, "set_param: query_parts must be 0 (automatic), 1 or 2");
+        ix->query_parts = (int)value;
         return 0;
     }
     if (!strcmp(name, "f32_scan")) {

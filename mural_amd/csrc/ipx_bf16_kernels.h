@@ -60,37 +60,50 @@ fuse_aspect_kernel(const float* __restrict__ src, const float* __restrict__ w, i
 }
 
 // row-major [n, d] (f32 / f16 / bf16) -> tiled, padded, swizzled bf16 (round to nearest even).
-// One thread per (row, 16-byte chunk of 8 bf16).
+// One thread per (row, 16-byte chunk of 8 bf16). parts == 2 (queries only) also writes the
+// residual lo = bf16(x - hi) as a second block behind each stage: x ~ hi + lo to 16 bits.
 __global__ void __launch_bounds__(256)
 pack_rows_bf16_kernel(const void* __restrict__ src, int dtype, int64_t n, int64_t n_pad, int d,
-                      uint16_t* __restrict__ dst, int64_t row0, int rows_per_tile, int nks) {
+                      uint16_t* __restrict__ dst, int64_t row0, int rows_per_tile, int nks, int parts) {
     const int nchunks = nks * 4;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t r = gid / nchunks;
     const int c = (int)(gid - r * nchunks);
     if (r >= n_pad) return;
-    uint16_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint16_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (r < n) {
         const int k0 = c * 8;
         const int64_t base = r * (int64_t)d;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             if (k0 + e < d) {
-                if (dtype == 2) v[e] = ((const uint16_t*)src)[base + k0 + e];
-                else v[e] = f32_to_bf16_rne(load_as_f32(src, dtype, base + k0 + e));
+                if (dtype == 2) {
+                    v[e] = ((const uint16_t*)src)[base + k0 + e];
+                } else {
+                    const float x = load_as_f32(src, dtype, base + k0 + e);
+                    v[e] = f32_to_bf16_rne(x);
+                    if (parts == 2) w[e] = f32_to_bf16_rne(x - __uint_as_float((uint32_t)v[e] << 16));
+                }
             }
     }
     const int64_t R = row0 + r;
     const int64_t tile = R / rows_per_tile;
     const int rr = (int)(R - tile * rows_per_tile);
     const int ks = c >> 2, pc = (c & 3) ^ ((rr >> 2) & 3);
-    uint16_t* o = dst + ((tile * nks + ks) * rows_per_tile + rr) * 32 + pc * 8;
+    uint16_t* o = dst + (((tile * nks + ks) * parts) * rows_per_tile + rr) * 32 + pc * 8;
     uint4 out;
     out.x = v[0] | ((uint32_t)v[1] << 16);
     out.y = v[2] | ((uint32_t)v[3] << 16);
     out.z = v[4] | ((uint32_t)v[5] << 16);
     out.w = v[6] | ((uint32_t)v[7] << 16);
     *(uint4*)o = out;
+    if (parts == 2) {
+        out.x = w[0] | ((uint32_t)w[1] << 16);
+        out.y = w[2] | ((uint32_t)w[3] << 16);
+        out.z = w[4] | ((uint32_t)w[5] << 16);
+        out.w = w[6] | ((uint32_t)w[7] << 16);
+        *(uint4*)(o + (size_t)rows_per_tile * 32) = out;
+    }
 }
 
 // max over rows of sum_i x_i^2 (fp32), as float bits in *maxsq (non-negative floats order like
@@ -129,31 +142,50 @@ __device__ __forceinline__ bf16x8 as_bf16x8(f32x4 v) { return __builtin_bit_cast
 // (large batches, MFMA-bound), 1 -> 64 queries per workgroup (small batches: a quarter of the
 // MFMA work per corpus byte and a deeper ring, so the corpus stream, not the matrix core, sets
 // the pace — the HBM-bound regime of BASELINE.json configs[4]).
-template <int QW> struct HCfg {
+// QP = bf16 parts per query: 1 -> q ~ bf16(q); 2 -> q ~ hi + lo with hi = bf16(q), lo = bf16(q - hi)
+// (16 significant bits: the query's rounding error all but vanishes from the margin, at twice
+// the MFMA work; both parts accumulate into the same fp32 accumulator).
+template <int QW, int QP> struct HCfg {
     static constexpr int BQ_ = 64 * QW;                  // queries per workgroup (2 wave columns)
-    static constexpr int STAGE_B = BQ_ * 64;
-    static constexpr int STAGE = HSTAGE_A + STAGE_B;     // 32 KiB / 20 KiB
-    static constexpr int NBUF = QW == 4 ? 4 : 6;         // LDS stage ring
-    static constexpr int LOADS = QW == 4 ? 4 : 3;        // LDS-DMA pieces per thread per stage
+    static constexpr int PART_B = BQ_ * 64;              // one part of the query stage
+    static constexpr int STAGE_B = PART_B * QP;
+    static constexpr int STAGE = HSTAGE_A + STAGE_B;     // 32 / 48 KiB (QW 4), 20 / 24 KiB (QW 1)
+    static constexpr int NBUF = QW == 4 ? (QP == 1 ? 4 : 3) : 6;      // LDS stage ring (<= 144 KiB)
+    static constexpr int LOADS = 2 + (QW == 4 ? 2 * QP : 1);          // LDS-DMA pieces per thread per stage
     static constexpr int RING = NBUF * STAGE;
 };
 
-template <int QW>
+// The copy pieces of one stage: A = 16 KiB contiguous = 2 rounds of 8 waves x 1 KiB; B = QP parts
+// of 16 KiB (QW 4: 2 rounds per part) or of 4 KiB (QW 1: with one part waves 4..7 repeat the
+// pieces of waves 0..3 — same bytes to the same place — and with two parts every wave has its own
+// piece; either way every wave issues the same number of copies, so one vmcnt count serves all).
+template <int QW, int QP>
+struct StagePieces {
+    const char* ga;     // this lane's 16 bytes of the wave's first A piece
+    const char* gb;     // ... of the wave's first B piece
+    char* la;           // the wave's first A piece in LDS (wave-uniform)
+    char* lb;
+    __device__ __forceinline__ StagePieces(const ScanParams& p, char* buf, int64_t tile, int qb, int ks, int wave, int lane) {
+        using C = HCfg<QW, QP>;
+        const int wb = (QW == 4 || QP == 2) ? wave : (wave & 3);
+        ga = (const char*)p.Xp + ((size_t)tile * p.nks + ks) * HSTAGE_A + wave * 1024 + lane * 16;
+        gb = (const char*)p.Qp + ((size_t)qb * p.nks + ks) * C::STAGE_B + wb * 1024 + lane * 16;
+        la = buf + wave * 1024;
+        lb = buf + HSTAGE_A + wb * 1024;
+    }
+    // piece i of HCfg::LOADS: 0, 1 = the A rounds; 2.. = the B rounds (8 KiB apart)
+    __device__ __forceinline__ void issue(int i) const {
+        if (i < 2) IPX_GLDS(ga + i * 8192, la + i * 8192);
+        else IPX_GLDS(gb + (i - 2) * 8192, lb + (i - 2) * 8192);
+    }
+};
+
+template <int QW, int QP>
 __device__ __forceinline__ void issue_stage_bf16(const ScanParams& p, char* buf, int64_t tile, int qb,
                                                  int ks, int wave, int lane) {
-    using C = HCfg<QW>;
-    // A stage: 16 KiB contiguous = 2 rounds of 8 waves x 1 KiB. B stage: 16 KiB likewise, or
-    // 4 KiB = one round in which waves 4..7 repeat the pieces of waves 0..3 (same bytes to the
-    // same place: every wave issues the same number of copies, so one vmcnt serves all).
-    const char* ga = (const char*)p.Xp + ((size_t)tile * p.nks + ks) * HSTAGE_A + wave * 1024 + lane * 16;
-    char* la = buf + wave * 1024;
-    IPX_GLDS(ga, la);
-    IPX_GLDS(ga + 8192, la + 8192);
-    const int wb = QW == 4 ? wave : (wave & 3);
-    const char* gb = (const char*)p.Qp + ((size_t)qb * p.nks + ks) * C::STAGE_B + wb * 1024 + lane * 16;
-    char* lb = buf + HSTAGE_A + wb * 1024;
-    IPX_GLDS(gb, lb);
-    if (QW == 4) IPX_GLDS(gb + 8192, lb + 8192);
+    const StagePieces<QW, QP> sp(p, buf, tile, qb, ks, wave, lane);
+#pragma unroll
+    for (int i = 0; i < HCfg<QW, QP>::LOADS; ++i) sp.issue(i);
 }
 
 template <int BQ_>
@@ -169,30 +201,62 @@ __device__ __forceinline__ void poll_union_threshold_n(const ScanParams& p, floa
 }
 
 template <int QW>
-__device__ __forceinline__ void read_set(f32x4 (&a)[2], f32x4 (&b)[QW], uint32_t aa, uint32_t bb) {
+__device__ __forceinline__ void read_a(f32x4 (&a)[2], uint32_t aa) {
     IPX_DS_READ_B128(a[0], aa, 0); IPX_DS_READ_B128(a[1], aa, 2048);
+}
+template <int QW>
+__device__ __forceinline__ void read_b(f32x4 (&b)[QW], uint32_t bb) {
     IPX_DS_READ_B128(b[0], bb, 0);
     if constexpr (QW == 4) {
         IPX_DS_READ_B128(b[1], bb, 2048); IPX_DS_READ_B128(b[2], bb, 4096); IPX_DS_READ_B128(b[3], bb, 6144);
     }
 }
-// s_waitcnt lgkmcnt(N) that the compiler sees as producing the operand registers
+// s_waitcnt lgkmcnt(N) that the compiler sees as (re)defining the operand registers waited for, so
+// no MFMA that consumes them can be moved above it
 template <int QW, int N>
-__device__ __forceinline__ void wait_set(f32x4 (&a)[2], f32x4 (&b)[QW]) {
+__device__ __forceinline__ void wait_ab(f32x4 (&a)[2], f32x4 (&b)[QW]) {
     if constexpr (QW == 4)
         asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
     else
         asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]) : "n"(N) : "memory");
+}
+template <int QW, int N>
+__device__ __forceinline__ void wait_b(f32x4 (&b)[QW]) {
+    if constexpr (QW == 4)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(b[0]) : "n"(N) : "memory");
+}
+// An empty asm that (to the compiler) reads and rewrites every accumulator: the MFMAs issued
+// before it cannot be sunk below it. Without this pin hipcc moves most of a phase's MFMAs behind
+// the later phases' operand reads, renames the operand registers to keep the old values alive,
+// spills, and the spill reloads' vmcnt(0) drains the copy pipeline every stage.
+template <int QW>
+__device__ __forceinline__ void pin_acc(f32x16 (&acc)[2][QW]) {
+    if constexpr (QW == 4)
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
+                          "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+    else
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]));
+}
+template <int QW>
+__device__ __forceinline__ void mfma_set(f32x16 (&acc)[2][QW], const f32x4 (&a)[2], const f32x4 (&b)[QW]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < QW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[i]), as_bf16x8(b[j]), acc[i][j], 0, 0, 0);
+    pin_acc<QW>(acc);
 }
 
 // Same streaming top-k machinery as scan_f32_kernel (queues, thresholds, compaction episodes,
 // union threshold); the tile shape, the stage ring and the MFMA differ. The pipeline keeps
 // NBUF - 1 stages in flight with counted vmcnt waits; the operand reads are issued from asm
 // (a compiler-visible LDS read after an LDS-DMA copy would get a vmcnt(0)).
-template <int QW>
+template <int QW, int QP>
 __global__ void __launch_bounds__(HTHREADS)
 scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
-    using C = HCfg<QW>;
+    using C = HCfg<QW, QP>;
     constexpr int BQ_ = C::BQ_, NBUF = C::NBUF, STAGE = C::STAGE, LOADS = C::LOADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int scratch_bytes = nsortwaves * p.cap * 8;
@@ -261,17 +325,21 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
 #pragma unroll
     for (int i = 1; i <= NBUF; ++i) cur[i] = advance(cur[i - 1]);
 #pragma unroll
-    for (int i = 0; i < NBUF; ++i) issue_stage_bf16<QW>(p, smem + i * STAGE, cur[i].t, qb, cur[i].ks, wave, lane);
+    for (int i = 0; i < NBUF; ++i) issue_stage_bf16<QW, QP>(p, smem + i * STAGE, cur[i].t, qb, cur[i].ks, wave, lane);
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 1)) : "memory");
     __syncthreads();
 
-    f32x4 a0[2], b0[QW], a1[2], b1[QW];
-    read_set<QW>(a0, b0, smem_base + a_off + pc0, smem_base + b_off + pc0);
+    // operand registers: A[s] = docs of K-set s (first / last 16 features of the stage); B[x] = a
+    // ping-pong pair of query operand sets. At the top of a stage A[0], B[0] hold set 0 (part hi).
+    f32x4 A[2][2], B[2][QW];
+    read_a<QW>(A[0], smem_base + a_off + pc0);
+    read_b<QW>(B[0], smem_base + b_off + pc0);
 
     int slot = 0, tiles_done = 0;
     // optional trace (ipx_set_param "trace"): wave 0's view of where the time goes
     uint64_t tr_epi = 0, tr_sort = 0, tr_begin = 0, tr_w1 = 0, tr_own = 0, tr_w2 = 0;
     uint32_t tr_appends = 0, tr_episodes = 0;
+    uint64_t tr_vm = 0, tr_bar = 0;
     if (p.trace) tr_begin = __builtin_readcyclecounter();
     while (cur[0].ok) {
         const int t = cur[0].t;
@@ -288,60 +356,85 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             const int nslot = slot + 1 == NBUF ? 0 : slot + 1;
             const uint32_t buf = smem_base + slot * STAGE;
             const uint32_t nbuf = smem_base + nslot * STAGE;
-            read_set<QW>(a1, b1, buf + a_off + pc1, buf + b_off + pc1);
-            // set 0 of this stage was read one half-stage ago
-            wait_set<QW, 2 + QW>(a0, b0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < QW; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0[i]), as_bf16x8(b0[j]), acc[i][j], 0, 0, 0);
+            constexpr int NB = QW;                 // LDS reads per B operand set
+            if constexpr (QP == 1) {
+                // first half: set 1 is read while set 0 (read one half-stage ago) is multiplied
+                read_a<QW>(A[1], buf + a_off + pc1);
+                read_b<QW>(B[1], buf + b_off + pc1);
+                wait_ab<QW, 2 + NB>(A[0], B[0]);
+                mfma_set<QW>(acc, A[0], B[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                wait_ab<QW, 0>(A[1], B[1]);
+            } else {
+                // three phases on this stage's buffer: (set 0, lo) | (set 1, hi) | (set 1, lo); each
+                // phase's operands are read while the previous phase is multiplied
+                read_b<QW>(B[1], buf + b_off + C::PART_B + pc0);
+                wait_ab<QW, NB>(A[0], B[0]);
+                mfma_set<QW>(acc, A[0], B[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                read_a<QW>(A[1], buf + a_off + pc1);
+                read_b<QW>(B[0], buf + b_off + pc1);
+                wait_b<QW, 2 + NB>(B[1]);
+                mfma_set<QW>(acc, A[0], B[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                read_b<QW>(B[1], buf + b_off + C::PART_B + pc1);
+                wait_ab<QW, NB>(A[1], B[0]);
+                mfma_set<QW>(acc, A[1], B[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                wait_b<QW, 0>(B[1]);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            // set 1 is in registers (so nobody reads this stage's buffer any more), the next
-            // stage has landed (NBUF - 2 younger stages may still be in flight)
-            wait_set<QW, 0>(a1, b1);
+            // the stage's last operands are in registers (so nobody reads its buffer any more), the
+            // next stage has landed (NBUF - 2 younger stages may still be in flight)
+#ifdef IPX_STAMP_BARRIER     // diagnostic build: cycles wave 0 spends in the per-stage wait + barrier
+            const uint64_t tb0 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
+            const uint64_t tb1 = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_barrier();
+            tr_vm += tb1 - tb0;
+            tr_bar += __builtin_readcyclecounter() - tb1;
+#else
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
             __builtin_amdgcn_s_barrier();
+#endif
             __builtin_amdgcn_sched_barrier(0);
-            // second half, in pinned issue order: the next stage's set-0 reads first (they have the
-            // whole half to land), then the copy pieces of the stage NBUF ahead spread among the
-            // MFMAs — a piece costs the wave ~60-180 issue cycles, which the matrix core spends on
-            // the MFMAs already queued (and on the other wave of this SIMD)
-            read_set<QW>(a0, b0, nbuf + a_off + pc0, nbuf + b_off + pc0);
+            // last phase, in pinned issue order: the next stage's first operands are read first (they
+            // have the whole phase to land), then the copy pieces of the stage NBUF ahead go out
+            // among the MFMAs — a piece costs the wave ~60-180 issue cycles, which the matrix core
+            // spends on the MFMAs already queued (and on the other wave of this SIMD)
+            read_a<QW>(A[0], nbuf + a_off + pc0);
+            read_b<QW>(B[0], nbuf + b_off + pc0);
             {
-                const StageCursor cn = cur[NBUF];
-                const char* ga = (const char*)p.Xp + ((size_t)cn.t * p.nks + cn.ks) * HSTAGE_A + wave * 1024 + lane * 16;
-                const int wb = QW == 4 ? wave : (wave & 3);
-                const char* gb = (const char*)p.Qp + ((size_t)qb * p.nks + cn.ks) * C::STAGE_B + wb * 1024 + lane * 16;
-                char* la = smem + slot * STAGE + wave * 1024;
-                char* lb = smem + slot * STAGE + HSTAGE_A + wb * 1024;
-#define IPX_MFMA1(i_, j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[i_]), as_bf16x8(b1[j_]), acc[i_][j_], 0, 0, 0)
+                const StagePieces<QW, QP> sp(p, smem + slot * STAGE, cur[NBUF].t, qb, cur[NBUF].ks, wave, lane);
+#define IPX_MFMA1(i_, j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A[1][i_]), as_bf16x8(B[1][j_]), acc[i_][j_], 0, 0, 0)
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (QW == 4) {
                     IPX_MFMA1(0, 0); IPX_MFMA1(0, 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    IPX_GLDS(ga, la);
+                    sp.issue(0);
                     __builtin_amdgcn_sched_barrier(0);
                     IPX_MFMA1(0, 2); IPX_MFMA1(0, 3);
                     __builtin_amdgcn_sched_barrier(0);
-                    IPX_GLDS(ga + 8192, la + 8192);
+                    sp.issue(1);
                     __builtin_amdgcn_sched_barrier(0);
                     IPX_MFMA1(1, 0); IPX_MFMA1(1, 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    IPX_GLDS(gb, lb);
+                    sp.issue(2);
+                    if constexpr (QP == 2) sp.issue(4);
                     __builtin_amdgcn_sched_barrier(0);
                     IPX_MFMA1(1, 2); IPX_MFMA1(1, 3);
                     __builtin_amdgcn_sched_barrier(0);
-                    IPX_GLDS(gb + 8192, lb + 8192);
+                    sp.issue(3);
+                    if constexpr (QP == 2) sp.issue(5);
                 } else {
                     IPX_MFMA1(0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    IPX_GLDS(ga, la);
+                    sp.issue(0);
                     __builtin_amdgcn_sched_barrier(0);
                     IPX_MFMA1(1, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    IPX_GLDS(ga + 8192, la + 8192);
-                    IPX_GLDS(gb, lb);
+                    sp.issue(1);
+                    sp.issue(2);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #undef IPX_MFMA1
@@ -403,7 +496,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             ++tr_episodes;
             // the sort scratch aliases the stage ring: let every copy land, sort, fetch the
             // NBUF stages again (cur[0]'s set-0 operands are already in registers)
-            wait_set<QW, 0>(a0, b0);
+            wait_ab<QW, 0>(A[0], B[0]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             uint64_t tr_a = 0, tr_b = 0;
@@ -420,7 +513,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
 #pragma unroll
             for (int i = 0; i < NBUF; ++i) {
                 const int sl = slot + i < NBUF ? slot + i : slot + i - NBUF;
-                issue_stage_bf16<QW>(p, smem + sl * STAGE, cur[i].t, qb, cur[i].ks, wave, lane);
+                issue_stage_bf16<QW, QP>(p, smem + sl * STAGE, cur[i].t, qb, cur[i].ks, wave, lane);
             }
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 1)) : "memory");
             __syncthreads();
@@ -440,7 +533,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             tr[1] = tr_epi;
             tr[2] = tr_sort;
             uint64_t* tx = p.trace + (size_t)gridDim.x * 4 + (size_t)blockIdx.x * 4;   // episode split (wave 0)
-            tx[0] = tr_w1; tx[1] = tr_own; tx[2] = tr_w2; tx[3] = 0;
+            tx[0] = tr_w1; tx[1] = tr_own; tx[2] = tr_w2 | (tr_vm << 32); tx[3] = tr_bar;
             atomicAdd((unsigned long long*)(tr + 3), (unsigned long long)tr_episodes);
         }
     }

@@ -9,7 +9,7 @@ if os.environ.get("IPX_LIB"):
 from mural_amd.faiss_retriever.retriever import FlatIPIndex
 
 dev = torch.device("cuda:0")
-for rows, nq, ms in [(16000, 2048, 1), (128000, 7168, 1), (2000000, 7168, 1), (2000000, 7168, 0), (8800000, 7168, 0)]:
+for rows, nq, ms in [(16000, 2048, 1), (2000000, 7168, 1), (2000000, 7168, 0)]:
     ix = FlatIPIndex(768, storage="bf16")
     ix.reserve(rows)
     g = torch.Generator(device=dev); g.manual_seed(1)
@@ -18,6 +18,7 @@ for rows, nq, ms in [(16000, 2048, 1), (128000, 7168, 1), (2000000, 7168, 1), (2
     Q = torch.randn((nq, 768), generator=g, device=dev)
     ix.set_timing(True)
     ix.set_param("max_splits", ms)
+    ix.set_param("query_parts", int(os.environ.get("QP", "0")))
     ts = []
     for it in range(4):
         try:

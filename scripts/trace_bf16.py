@@ -2,6 +2,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from mural_amd import _lib as _l
+if os.environ.get('IPX_LIB'):
+    _l.LIB_PATH = os.path.join(os.path.dirname(_l.LIB_PATH), os.environ['IPX_LIB'])
 from mural_amd.faiss_retriever.retriever import FlatIPIndex
 dev = torch.device("cuda:0")
 rows, nq = int(sys.argv[1]), int(sys.argv[2])
@@ -12,7 +15,7 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 for lo in range(0, rows, 200000):
     ix.add(torch.randn((min(200000, rows - lo), 768), generator=g, device=dev))
 Q = torch.randn((nq, 768), generator=g, device=dev)
-ix.set_timing(True); ix.set_param("trace", 1)
+ix.set_timing(True); ix.set_param("trace", 1); ix.set_param("query_parts", int(os.environ.get("QP", "0")))
 for it in range(2):
     ix.search_device(Q, 100); torch.cuda.synchronize()
 import ctypes as C
@@ -29,3 +32,6 @@ print(f"per WG mean: total {tot.mean():.3e} ticks, filter {epi.mean()/tot.mean()
       f"appends {app.mean():.0f} ({app.mean()/tiles:.1f}/tile), episodes {eps.mean():.1f} (max {eps.max():.0f})")
 print(f"episode split (wave 0, share of total): wait for the other waves' filters {ex[:,0].mean()/tot.mean():.3f}, own compaction {ex[:,1].mean()/tot.mean():.3f}, "
       f"wait for the other waves' compaction {ex[:,2].mean()/tot.mean():.3f}")
+if os.environ.get("IPX_LIB"):
+    vm = (raw[n:, 2] >> np.uint64(32)).astype(np.float64); bar = ex[:, 3]
+    print(f"per-stage waits (wave 0, share of total): vmcnt {vm.mean()/tot.mean():.3f}, barrier {bar.mean()/tot.mean():.3f}")

@@ -60,7 +60,7 @@ def test_bf16scan_is_bit_identical_to_the_fp32_scan(R, n, d, nq, k, adds):
     assert D.dtype == np.float32 and I.dtype == np.int64 and D.shape == (nq, k) == I.shape
     assert_bits(D, I, Q, X, k)
     st = ix.last_bf16_stats()
-    assert (st["candidates"] > 0) == (4 * k <= 2048)
+    assert st["candidates"] >= min(k, 2048)          # every depth takes the bf16 scan (hi + lo query parts when deep)
     # same index, fp32 scan forced: the two scans of one index agree bit for bit
     ix.set_param("f32_scan", 1)
     D2, I2 = ix.search(Q, k)
@@ -84,6 +84,17 @@ def test_bf16_rows_exact_on_the_stored_values(R, n, d, nq, k):
     ix2.add(t)
     D2, I2 = ix2.search(Q, k)
     assert np.array_equal(I, I2) and np.array_equal(D.view(np.uint32), D2.view(np.uint32))
+
+
+@pytest.mark.parametrize("parts", [1, 2])
+@pytest.mark.parametrize("n,d,nq,k", [(30000, 768, 300, 100), (9000, 100, 64, 300), (50000, 64, 20, 1000)])
+def test_query_parts_do_not_change_results(R, parts, n, d, nq, k):
+    X, Q = gaussian(21, (n, d)), gaussian(22, (nq, d))
+    for storage, ref in (("bf16scan", X), ("bf16", bf16_round(X))):
+        ix = index(R, X, storage)
+        ix.set_param("query_parts", parts)
+        D, I = ix.search(Q, k)
+        assert_bits(D, I, Q, ref, k)
 
 
 def test_short_candidate_lists_are_caught_and_repeated(R):
