@@ -172,6 +172,22 @@ def main():
                          "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": 2.0 * nq * (hi - lo) * d / (sc2a * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                          "kernel": "scan_bf16_kernel<4>"}}
+        # the reference's default depth (--depth 1000, src/pretrain_finetune1.sh:218-228): hi + lo query parts
+        k_deep = 1000
+        old_k = k
+        k = k_deep
+        el4, sc4, D4, I4 = timed(Q, 2, 1)
+        bf4 = ix.last_bf16_stats()
+        ix.set_param("f32_scan", 1)
+        el5, sc5, D5, I5 = timed(Q, 2, 1)
+        ix.set_param("f32_scan", 0)
+        k = old_k
+        extra["depth_1000"] = {
+            "what": "top-1000 on the same index: bf16 scan with hi+lo query parts + fp32 rescoring vs the fp32 scan",
+            "bit_identical": bool(torch.equal(I4, I5)) and bool(torch.equal(D4.view(torch.int32), D5.view(torch.int32))),
+            "bf16scan_queries_per_s": nq / (el4 / 2), "bf16scan_ms": el4 * 1e3 / 2, "bf16_scan_kernel_ms": sum(sc4) / len(sc4),
+            "candidates": bf4["candidates"], "repeated_queries": bf4["fallback_queries"], "rescore_ms": round(bf4["rescore_ms"], 3),
+            "f32_queries_per_s": nq / (el5 / 2), "f32_ms": el5 * 1e3 / 2, "f32_scan_kernel_ms": sum(sc5) / len(sc5)}
         small = []
         for bnq in (1, 16, 64):
             el3, sc3, _, _ = timed(Q[:bnq].contiguous(), 20, 3)
