@@ -386,6 +386,12 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             __builtin_amdgcn_sched_barrier(0);
             // the stage's last operands are in registers (so nobody reads its buffer any more), the
             // next stage has landed (NBUF - 2 younger stages may still be in flight)
+#define IPX_MFMA1(i_, j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A[1][i_]), as_bf16x8(B[1][j_]), acc[i_][j_], 0, 0, 0)
+            // the addresses of the next copy pieces are worked out before the barrier, and the first
+            // MFMAs of the last phase go out right behind it: the matrix core has work queued while
+            // this wave issues the next stage's operand reads
+            const StagePieces<QW, QP> sp(p, smem + slot * STAGE, cur[NBUF].t, qb, cur[NBUF].ks, wave, lane);
+            __builtin_amdgcn_sched_barrier(0);
 #ifdef IPX_STAMP_BARRIER     // diagnostic build: cycles wave 0 spends in the per-stage wait + barrier
             const uint64_t tb0 = __builtin_readcyclecounter();
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
@@ -398,18 +404,16 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             __builtin_amdgcn_s_barrier();
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            // last phase, in pinned issue order: the next stage's first operands are read first (they
-            // have the whole phase to land), then the copy pieces of the stage NBUF ahead go out
+            // last phase, in pinned issue order: two MFMAs, the next stage's first operand reads (they
+            // have the rest of the phase to land), then the copy pieces of the stage NBUF ahead
             // among the MFMAs — a piece costs the wave ~60-180 issue cycles, which the matrix core
             // spends on the MFMAs already queued (and on the other wave of this SIMD)
-            read_a<QW>(A[0], nbuf + a_off + pc0);
-            read_b<QW>(B[0], nbuf + b_off + pc0);
             {
-                const StagePieces<QW, QP> sp(p, smem + slot * STAGE, cur[NBUF].t, qb, cur[NBUF].ks, wave, lane);
-#define IPX_MFMA1(i_, j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A[1][i_]), as_bf16x8(B[1][j_]), acc[i_][j_], 0, 0, 0)
-                __builtin_amdgcn_sched_barrier(0);
                 if constexpr (QW == 4) {
                     IPX_MFMA1(0, 0); IPX_MFMA1(0, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_a<QW>(A[0], nbuf + a_off + pc0);
+                    read_b<QW>(B[0], nbuf + b_off + pc0);
                     __builtin_amdgcn_sched_barrier(0);
                     sp.issue(0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -428,6 +432,9 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
                     if constexpr (QP == 2) sp.issue(5);
                 } else {
                     IPX_MFMA1(0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_a<QW>(A[0], nbuf + a_off + pc0);
+                    read_b<QW>(B[0], nbuf + b_off + pc0);
                     __builtin_amdgcn_sched_barrier(0);
                     sp.issue(0);
                     __builtin_amdgcn_sched_barrier(0);
