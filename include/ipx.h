@@ -110,7 +110,7 @@ int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in
  *                    candidate list cannot be proven sufficient are repeated on the fp32 scan).
  *                  2 bf16 rows only (rows given as bf16 are kept exactly, fp32 / f16 rows are
  *                    rounded to nearest even): bf16 scan, then exact fp32 scores of
- *                    <fp32 query, stored bf16 row>; half the HBM of storage 0.
+ *                    <fp32 query, stored bf16 row>; half the HBM of storage 0; k <= 1638.
  *   "bf16_candidates" : candidates per query the bf16 scan keeps (0 = automatic).
  *   "query_parts": bf16 parts per query in the bf16 scan: 1 = bf16(q); 2 = hi + lo (16 bits of
  *                  the query, twice the MFMA work, a far smaller margin); 0 = automatic.

@@ -601,9 +601,14 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
     } else {
         if (int rc = ix->err.ensure(256)) return rc;
         IPX_HIP(hipMemsetAsync(ix->err.p, 0, 256, st));
-        // bf16 scan whenever the index keeps a bf16 copy
+        // bf16 scan whenever the index keeps a bf16 copy and the candidate list (2k with hi + lo
+        // query parts, 1.25k on bf16 rows) fits IPX_MAX_K; deeper searches take the fp32 scan,
+        // which bf16-only storage does not have
+        if (ix->storage == 2 && k > IPX_MAX_K * 4 / 5 && ix->force_kc == 0)
+            return fail(IPX_ERR_ARG, "search: bf16 storage serves k <= " + std::to_string(IPX_MAX_K * 4 / 5) +
+                        " (the candidate list is 1.25 k); use storage 0 or 1 for deeper searches");
         const bool bf16 = ix->storage == 2 ||
-                          (ix->storage == 1 && !ix->force_f32_scan);
+                          (ix->storage == 1 && !ix->force_f32_scan && (2 * k <= IPX_MAX_K || ix->force_kc > 0));
         int rc = bf16 ? scan_bf16_path(ix, dq, dw, A, logits, nq, k, dD, dI, st)
                       : scan_f32_path(ix, dq, dw, A, logits, nq, k, dD, dI, st, true);
         if (rc) return rc;

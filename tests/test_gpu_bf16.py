@@ -50,7 +50,8 @@ def assert_bits(D, I, Q, X, k):
     (4096, 768, 32, 1, 1), (4096, 768, 32, 100, 1), (5000, 768, 300, 100, 2),
     (20000, 100, 513, 100, 3),        # d not a multiple of 32, three adds, three query blocks
     (9000, 17, 64, 512, 2),           # 4k = 2048 candidates: the longest list
-    (9000, 48, 64, 1000, 1),          # 4k > limit: storage 1 goes straight to the fp32 scan
+    (9000, 48, 64, 1000, 1),          # hi + lo query parts, 2000 candidates
+    (9000, 48, 64, 1500, 1),          # 2k > limit: storage 1 goes straight to the fp32 scan
     (777, 768, 1, 100, 1), (255, 16, 257, 5, 1), (257, 16, 256, 300, 1), (1, 8, 3, 4, 1),
 ])
 def test_bf16scan_is_bit_identical_to_the_fp32_scan(R, n, d, nq, k, adds):
@@ -60,7 +61,7 @@ def test_bf16scan_is_bit_identical_to_the_fp32_scan(R, n, d, nq, k, adds):
     assert D.dtype == np.float32 and I.dtype == np.int64 and D.shape == (nq, k) == I.shape
     assert_bits(D, I, Q, X, k)
     st = ix.last_bf16_stats()
-    assert st["candidates"] >= min(k, 2048)          # every depth takes the bf16 scan (hi + lo query parts when deep)
+    assert (st["candidates"] > 0) == (2 * k <= 2048)  # depths whose 2k candidates fit take the bf16 scan
     # same index, fp32 scan forced: the two scans of one index agree bit for bit
     ix.set_param("f32_scan", 1)
     D2, I2 = ix.search(Q, k)
@@ -165,6 +166,17 @@ def test_bf16scan_aspect_queries_and_float16_rows(R):
         D1, I1 = b.search_aspect(E, logits, 100, **kw)
         assert b.last_bf16_stats()["candidates"] == 400
         assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
+
+
+def test_depth_limits_of_the_bf16_storage(R):
+    from mural_amd._lib import IpxError
+    X, Q = gaussian(31, (6000, 32)), gaussian(32, (10, 32))
+    ix = index(R, X, "bf16")
+    D, I = ix.search(Q, 1638)
+    assert_bits(D, I, Q, bf16_round(X), 1638)
+    with pytest.raises(IpxError) as e:
+        ix.search(Q, 1639)
+    assert e.value.code == 1 and "1638" in str(e.value)
 
 
 def test_storage_can_only_be_chosen_on_an_empty_index(R):
