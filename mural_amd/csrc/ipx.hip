@@ -450,7 +450,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     rp.k = k;
     rp.kc = kc;
     rp.P = next_pow2(kc);
-    const int rlds = ((rp.nks * (rp.x_is_bf16 ? 32 : 16) * 4 + 15) & ~15) + rp.P * 8;
+    const int rlds = ((rp.nks * (rp.x_is_bf16 ? 32 : 16) * 4 + 15) & ~15) + rp.P * 8 + 4 * ipx::RS_KB * 16 * ipx::RS_ROW;
     if (rlds > 64 * 1024)
         IPX_HIP(hipFuncSetAttribute((const void*)ipx::rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rlds));
     hipLaunchKernelGGL(ipx::rescore_kernel, dim3((unsigned)nq), dim3(256), rlds, st, rp);

@@ -577,50 +577,11 @@ struct RescoreParams {
     int d, nks, x_is_bf16, k, kc, P;
 };
 
-__device__ __forceinline__ float exact_score_f32rows(const float* X, int nks, int64_t row, const float* q) {
-    const int64_t tile = row / BD;
-    const int rr = (int)(row - tile * BD);
-    const int sw = (rr >> 2) & 3;
-    const float* base = X + ((size_t)tile * nks * BD + rr) * 16;
-    float acc = 0.f;
-    for (int ks = 0; ks < nks; ++ks) {
-        const float* st = base + (size_t)ks * BD * 16;
-        const f32x4 c0 = *(const f32x4*)(st + ((0 ^ sw) << 2)), c1 = *(const f32x4*)(st + ((1 ^ sw) << 2));
-        const f32x4 c2 = *(const f32x4*)(st + ((2 ^ sw) << 2)), c3 = *(const f32x4*)(st + ((3 ^ sw) << 2));
-        const float* qq = q + ks * 16;
-        // MFMA 32x32x2 order inside a group of 8 features: 0,4,1,5,2,6,3,7
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { acc = fmaf(c0[e], qq[e], acc); acc = fmaf(c1[e], qq[4 + e], acc); }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { acc = fmaf(c2[e], qq[8 + e], acc); acc = fmaf(c3[e], qq[12 + e], acc); }
-    }
-    return acc;
-}
-
 __device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-__device__ __forceinline__ float exact_score_bf16rows(const uint16_t* X, int nks, int64_t row, const float* q) {
-    const int64_t tile = row / HBD;
-    const int rr = (int)(row - tile * HBD);
-    const int sw = (rr >> 2) & 3;
-    const uint16_t* base = X + ((size_t)tile * nks * HBD + rr) * 32;
-    float acc = 0.f;
-    for (int ks = 0; ks < nks; ++ks) {
-        const uint16_t* st = base + (size_t)ks * HBD * 32;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint4 v = *(const uint4*)(st + ((c ^ sw) << 3));
-            const float* qq = q + ks * 32 + c * 8;
-            // features 0..7 of the chunk: x = lo(v.x), hi(v.x), lo(v.y), hi(v.y), lo(v.z), ...
-            acc = fmaf(bf16_lo(v.x), qq[0], acc); acc = fmaf(bf16_lo(v.z), qq[4], acc);
-            acc = fmaf(bf16_hi(v.x), qq[1], acc); acc = fmaf(bf16_hi(v.z), qq[5], acc);
-            acc = fmaf(bf16_lo(v.y), qq[2], acc); acc = fmaf(bf16_lo(v.w), qq[6], acc);
-            acc = fmaf(bf16_hi(v.y), qq[3], acc); acc = fmaf(bf16_hi(v.w), qq[7], acc);
-        }
-    }
-    return acc;
-}
+constexpr int RS_KB = 4;        // K-stages fetched per round
+constexpr int RS_ROW = 80;      // LDS bytes per staged 64-byte line (80: 16 lines, 16 different bank groups)
 
 __global__ void __launch_bounds__(256)
 rescore_kernel(const RescoreParams p) {
@@ -669,15 +630,67 @@ rescore_kernel(const RescoreParams p) {
     }
     __syncthreads();
     const int m = s_m;
-    for (int i = tid; i < p.P; i += 256) {
-        uint64_t key = 0;
-        if (i < m) {
-            const int64_t row = cI[i] - p.id_base;
-            const float s = p.x_is_bf16 ? exact_score_bf16rows((const uint16_t*)p.X, p.nks, row, qs)
-                                        : exact_score_f32rows((const float*)p.X, p.nks, row, qs);
-            if (s > -FLT_MAX) key = make_key(s, (uint32_t)row);   // the fp32 scan's admission rule
+    // Exact scores, 16 candidates per wave at a time. A candidate row is 64 contiguous bytes per
+    // K-stage, stages one tile-stage block apart: four lanes fetch one such line (16 bytes each),
+    // so a wave instruction brings 16 whole lines — one request per line instead of four partial
+    // ones — for RS_KB K-stages in a row; the lines go through LDS to lane r < 16, which owns
+    // candidate r and runs the ordered fmaf chain (the order of the fp32 scan's MFMA).
+    for (int i = tid; i < p.P; i += 256) keys[i] = 0;
+    char* stage = (char*)(keys + p.P) + wave * (RS_KB * 16 * RS_ROW);
+    const int R = p.x_is_bf16 ? HBD : BD;                 // rows per tile of the packed layout
+    const size_t ks_stride = (size_t)R * 64;              // bytes between a row's consecutive K-stages
+    for (int g0 = wave * 16; g0 < m; g0 += 64) {
+        const int r = lane >> 2, pc = lane & 3;
+        const int ci = g0 + r < m ? g0 + r : m - 1;
+        const int64_t row = cI[ci] - p.id_base;
+        const int64_t tile = row / R;
+        const int rr = (int)(row - tile * R);
+        const char* src = (const char*)p.X + ((size_t)tile * p.nks * R + rr) * 64 + pc * 16;
+        // lane r < 16 computes candidate g0 + r: its row's swizzle
+        const int my = g0 + lane < m ? g0 + lane : m - 1;
+        const int64_t myrow = lane < 16 ? cI[my] - p.id_base : 0;
+        const int mysw = (int)(((myrow % R) >> 2) & 3);
+        float acc = 0.f;
+        for (int ks0 = 0; ks0 < p.nks; ks0 += RS_KB) {
+            uint4 v[RS_KB];
+#pragma unroll
+            for (int u = 0; u < RS_KB; ++u) {
+                const int ks = ks0 + u < p.nks ? ks0 + u : p.nks - 1;
+                v[u] = *(const uint4*)(src + (size_t)ks * ks_stride);
+            }
+#pragma unroll
+            for (int u = 0; u < RS_KB; ++u) *(uint4*)(stage + (u * 16 + r) * RS_ROW + pc * 16) = v[u];
+            wave_lds_sync();
+            if (lane < 16) {
+                const int nb = p.nks - ks0 < RS_KB ? p.nks - ks0 : RS_KB;
+                for (int u = 0; u < nb; ++u) {
+                    const char* line = stage + (u * 16 + lane) * RS_ROW;
+                    if (!p.x_is_bf16) {
+                        const f32x4 c0 = *(const f32x4*)(line + ((0 ^ mysw) << 4)), c1 = *(const f32x4*)(line + ((1 ^ mysw) << 4));
+                        const f32x4 c2 = *(const f32x4*)(line + ((2 ^ mysw) << 4)), c3 = *(const f32x4*)(line + ((3 ^ mysw) << 4));
+                        const float* qq = qs + (ks0 + u) * 16;
+                        // MFMA 32x32x2 order inside a group of 8 features: 0,4,1,5,2,6,3,7
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { acc = fmaf(c0[e], qq[e], acc); acc = fmaf(c1[e], qq[4 + e], acc); }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { acc = fmaf(c2[e], qq[8 + e], acc); acc = fmaf(c3[e], qq[12 + e], acc); }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const uint4 w = *(const uint4*)(line + ((c ^ mysw) << 4));
+                            const float* qq = qs + (ks0 + u) * 32 + c * 8;
+                            acc = fmaf(bf16_lo(w.x), qq[0], acc); acc = fmaf(bf16_lo(w.z), qq[4], acc);
+                            acc = fmaf(bf16_hi(w.x), qq[1], acc); acc = fmaf(bf16_hi(w.z), qq[5], acc);
+                            acc = fmaf(bf16_lo(w.y), qq[2], acc); acc = fmaf(bf16_lo(w.w), qq[6], acc);
+                            acc = fmaf(bf16_hi(w.y), qq[3], acc); acc = fmaf(bf16_hi(w.w), qq[7], acc);
+                        }
+                    }
+                }
+            }
+            wave_lds_sync();
         }
-        keys[i] = key;
+        if (lane < 16 && g0 + lane < m && acc > -FLT_MAX)        // the fp32 scan's admission rule
+            keys[g0 + lane] = make_key(acc, (uint32_t)myrow);
     }
     __syncthreads();
     for (int size = 2; size <= p.P; size <<= 1)
