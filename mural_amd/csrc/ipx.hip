@@ -508,12 +508,15 @@ int redo_queries(ipx_index* ix, const float* qf, const std::vector<int>& sel, in
 int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
                    float* dD, int64_t* dI, hipStream_t st) {
     const int d = ix->d;
-    // One bf16 part per query and 4k candidates (2k when only the query is rounded) while that
+    // One bf16 part per query and 5k candidates (2k when only the query is rounded) while that
     // list stays short; deeper searches split the query into hi + lo parts — the margin then only
     // carries the rows' rounding (none in storage 2) — and keep 2k (1.25k) candidates.
-    int qparts = ix->query_parts > 0 ? ix->query_parts : ((ix->storage == 2 ? 2 : 4) * k > 1024 ? 2 : 1);
+    // (Gaussian 768-d rows, k = 100: the margin set holds ~270 rows; 4k left 2 of 6980 queries
+    // to the repeat pass, 4.5k and up none.)
+    const int mult1 = ix->storage == 2 ? 2 : 5;
+    int qparts = ix->query_parts > 0 ? ix->query_parts : (mult1 * k > 1024 ? 2 : 1);
     int kc = ix->force_kc > 0 ? ix->force_kc
-             : qparts == 1 ? std::max(256, (ix->storage == 2 ? 2 : 4) * k)
+             : qparts == 1 ? std::max(256, mult1 * k)
                            : std::max(256, ix->storage == 2 ? k + k / 4 : 2 * k);
     kc = std::min(std::max(kc, k), (int)IPX_MAX_K);
 

@@ -164,7 +164,7 @@ def test_bf16scan_aspect_queries_and_float16_rows(R):
     for kw in ({"logits": True},):
         D0, I0 = a.search_aspect(E, logits, 100, **kw)
         D1, I1 = b.search_aspect(E, logits, 100, **kw)
-        assert b.last_bf16_stats()["candidates"] == 400
+        assert b.last_bf16_stats()["candidates"] == 500
         assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
 
 
@@ -205,7 +205,7 @@ def test_config2_scale_bf16scan_equals_fp32_scan(R):
     Q = torch.randn((nq, d), generator=g, device=dev, dtype=torch.float32)
     D1, I1 = ix.search_device(Q, k)
     st = ix.last_bf16_stats()
-    assert st["candidates"] == 400 and st["fallback_queries"] < nq // 50
+    assert st["candidates"] == 500 and st["fallback_queries"] < nq // 50
     ix.set_param("f32_scan", 1)
     D0, I0 = ix.search_device(Q, k)
     ix.check()
