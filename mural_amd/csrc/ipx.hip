@@ -513,8 +513,12 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     // carries the rows' rounding (none in storage 2) — and keep 2k (1.25k) candidates.
     // (Gaussian 768-d rows, k = 100: the margin set holds ~270 rows; 4k left 2 of 6980 queries
     // to the repeat pass, 4.5k and up none.)
+    // Batches of up to 64 queries are bound by the corpus stream, not the matrix core: the second
+    // query part is free there, and its short list (<= the number of splits) lets every split
+    // publish just its best score (scan_bf16_kernel, fast1).
     const int mult1 = ix->storage == 2 ? 2 : 5;
-    int qparts = ix->query_parts > 0 ? ix->query_parts : (mult1 * k > 1024 ? 2 : 1);
+    const bool small = nq <= 64 && !ix->no_small_batch;
+    int qparts = ix->query_parts > 0 ? ix->query_parts : ((small || mult1 * k > 1024) ? 2 : 1);
     int kc = ix->force_kc > 0 ? ix->force_kc
              : qparts == 1 ? std::max(256, mult1 * k)
                            : std::max(256, ix->storage == 2 ? k + k / 4 : 2 * k);

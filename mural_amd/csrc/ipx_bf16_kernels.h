@@ -280,6 +280,15 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
     if (tid < 2) flags[tid] = 0;
     uint32_t* mypub = p.S > 1 ? p.pub + ((size_t)qb * p.S + split) * BQ_ : nullptr;
     const int fill_limit = p.cap - 2 * HBD;
+    // Small batches with at least as many splits as candidates (r == 1: every split publishes its
+    // single best score): the best score per query is kept by an LDS max beside the appends and
+    // published / polled at 1, 2, 4, 8, ... tiles without touching the queues — no compaction
+    // episodes at all unless a queue fills. (Each split sees only N / S rows, so its own k-th best
+    // is a poor threshold anyway; the union bound is the one that prunes.)
+    uint32_t* best = (uint32_t*)(flags + 4);              // [BQ_]   (QW == 1 only)
+    uint32_t* tmin = best + BQ_;                          // [BQ_]
+    const bool fast1 = QW == 1 && p.S > 1 && p.r == 1;
+    if (QW == 1 && tid < BQ_) best[tid] = 0;
 
     uint64_t* myqueues = p.cand + (size_t)blockIdx.x * BQ_ * p.cap;
     uint64_t* scratch = (uint64_t*)smem + (size_t)wave * p.cap;
@@ -490,6 +499,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
                                 if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
                                 else *p.err = 1;
                                 if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
+                                if constexpr (QW == 1) lds_atomic_max_u32_nodma(&best[ql], f32_ordered(sc));
                                 ++tr_appends;
                             }
                         }
@@ -498,7 +508,45 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
         }
         uint64_t tr_e1 = 0;
         if (p.trace) { tr_e1 = __builtin_readcyclecounter(); tr_epi += tr_e1 - tr_e0; }
-        episode = episode || is_pow4(tiles_done);
+        if constexpr (QW == 1) {
+            if (fast1 && ((tiles_done & (tiles_done - 1)) == 0 || (tiles_done & 31) == 0)) {
+                // publish this split's best, take the minimum over all splits as the new floor.
+                // After the first tile every split starts at the same time: wait (bounded) until
+                // all of them have published, so the second tile already runs against a bound.
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid < BQ_) {
+                    const uint32_t b = best[tid];
+                    if (b) __hip_atomic_store(mypub + tid, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const int q = tid & (BQ_ - 1), part = tid / BQ_;           // 8 threads per query
+                const int per = (p.S + 7) / 8;
+                const int s_lo = part * per, s_hi = s_lo + per < p.S ? s_lo + per : p.S;
+                const uint32_t* col = p.pub + (size_t)qb * p.S * BQ_ + q;
+                for (int attempt = 0; attempt < (tiles_done == 1 ? 64 : 1); ++attempt) {
+                    if (tid < BQ_) tmin[tid] = 0xffffffffu;
+                    __syncthreads();
+                    uint32_t v = 0xffffffffu;
+#pragma unroll 8
+                    for (int s2 = s_lo; s2 < s_hi; ++s2) {
+                        const uint32_t x = __hip_atomic_load(col + (size_t)s2 * BQ_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v = x < v ? x : v;
+                    }
+                    atomicMin(&tmin[q], v);
+                    __syncthreads();
+                    // queries beyond nq never publish: they do not count as "missing"
+                    const bool missing = tid < BQ_ && (int64_t)qb * BQ_ + tid < p.nq && tmin[tid] == 0;
+                    if (!__syncthreads_or(missing)) break;
+                    __builtin_amdgcn_s_sleep(20);
+                }
+                if (tid < BQ_) {
+                    const uint32_t v = tmin[tid];
+                    if (v != 0 && v != 0xffffffffu) taus[tid] = fmaxf(taus[tid], f32_below(f32_unordered(v)));
+                }
+                __syncthreads();
+            }
+        }
+        episode = episode || (is_pow4(tiles_done) && !fast1);
         if (episode) {
             ++tr_episodes;
             // the sort scratch aliases the stage ring: let every copy land, sort, fetch the

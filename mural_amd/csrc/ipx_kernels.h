@@ -77,6 +77,11 @@ __device__ __forceinline__ int lds_atomic_inc_nodma(int* p) {
     return old;
 }
 
+__device__ __forceinline__ void lds_atomic_max_u32_nodma(uint32_t* p, uint32_t v) {
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)p;
+    asm volatile("ds_max_u32 %0, %1" : : "v"(a), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ int lds_read_i32_nodma(const int* p) {
     int v;
     const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) int*)p;
