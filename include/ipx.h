@@ -93,6 +93,25 @@ int ipx_search_aspect(ipx_index* idx, const float* aspect_emb, const float* w, i
                       int w_is_logits, int64_t nq, int k,
                       float* out_D, int64_t* out_I, int on_device, void* stream);
 
+/* The MURAL pooler on the device: what MULGRAIN_Pooler.forward ('att' pooling) computes from the
+ * encoder's last hidden states                         modeling/mul_grain.py:97-110 (queries), :117-132 (docs)
+ *   att = softmax(W h[:,0] + b)        W: fp32 [A, d], b: fp32 [A]   (cls_linear_q / cls_linear_d of pooler.pt)
+ *   rep = sum_a att[a] * h[:, begin_id + a]
+ * hidden: fp32 [n, seq_len, d], d = ipx_dim(idx) (only row 0 and rows begin_id .. begin_id+A-1 of each
+ * sequence are read); out_att (may be NULL): fp32 [n, A], the weights the reference returns as q_att / doc_att.
+ * The reference pools at encode time (driver/encode.py:275-278, modeling/encoder.py) and stores rep in the
+ * pickles; with these three the encoder's output goes straight into the index or the search.
+ *   ipx_pool          rep -> out_rep fp32 [n, d]
+ *   ipx_add_pooled    rep appended like ipx_add
+ *   ipx_search_pooled rep searched like ipx_search */
+int ipx_pool(ipx_index* idx, const float* hidden, int64_t seq_len, const float* W, const float* b, int A,
+             int begin_id, int64_t n, float* out_rep, float* out_att, int on_device, void* stream);
+int ipx_add_pooled(ipx_index* idx, const float* hidden, int64_t seq_len, const float* W, const float* b, int A,
+                   int begin_id, int64_t n, int on_device, void* stream);
+int ipx_search_pooled(ipx_index* idx, const float* hidden, int64_t seq_len, const float* W, const float* b, int A,
+                      int begin_id, int64_t nq, int k, float* out_D, int64_t* out_I, float* out_att,
+                      int on_device, void* stream);
+
 /* Replaces faiss.ResultHeap(nq,k).add_result(-D_s, I_s) for s in shards; finalize()
  *                                                      reducer.py:15-18
  * D: fp32 [S, nq, k_in], I: int64 [S, nq, k_in] (one block per shard, ids already

@@ -75,7 +75,7 @@ struct ipx_index {
     int64_t cap_tiles_h = 0; // tiles of 256 rows the bf16 buffer holds
     uint16_t* Xh = nullptr;  // packed bf16 corpus (storage 1, 2)
     DevBuf Qp, cand, partD, partI, err, stageIn, stageQ, stageW, outD, outI, trace, pub;
-    DevBuf maxsq, qfused, candD, candI, flags, sel, qsel, selD, selI;
+    DevBuf maxsq, qfused, candD, candI, flags, sel, qsel, selD, selI, poolH, poolW, poolQ;
     void* pinned = nullptr;          // host staging of ipx_add (two slices)
     size_t pinned_bytes = 0;
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
@@ -674,7 +674,7 @@ int ipx_destroy(ipx_index* ix) {
     if (ix->Xh) (void)hipFree(ix->Xh);
     for (DevBuf* b : {&ix->Qp, &ix->cand, &ix->partD, &ix->partI, &ix->err, &ix->stageIn, &ix->stageQ, &ix->stageW,
                       &ix->outD, &ix->outI, &ix->trace, &ix->pub, &ix->maxsq, &ix->qfused, &ix->candD, &ix->candI,
-                      &ix->flags, &ix->sel, &ix->qsel, &ix->selD, &ix->selI})
+                      &ix->flags, &ix->sel, &ix->qsel, &ix->selD, &ix->selI, &ix->poolH, &ix->poolW, &ix->poolQ})
         b->release();
     for (auto& e : ix->ev)
         if (e) (void)hipEventDestroy(e);
@@ -775,6 +775,84 @@ int ipx_search_aspect(ipx_index* ix, const float* aspect_emb, const float* w, in
                       int k, float* out_D, int64_t* out_I, int on_device, void* stream) {
     if (A <= 0 || A > 64) return fail(IPX_ERR_ARG, "search_aspect: A outside [1, 64]");
     return search_impl(ix, aspect_emb, w, A, w_is_logits ? 1 : 0, nq, k, out_D, out_I, on_device, stream);
+}
+
+// MURAL 'att' pooling of n sequences into ix->poolQ (fp32 [n, d]); attention weights behind W and b in ix->poolW.
+static int pool_impl(ipx_index* ix, const char* who, const float* hidden, int64_t seq_len, const float* W, const float* b,
+                     int A, int begin_id, int64_t n, float* out_att, int on_device, hipStream_t st) {
+    if (!ix) return fail(IPX_ERR_ARG, std::string(who) + ": null index");
+    if (A <= 0 || A > 64) return fail(IPX_ERR_ARG, std::string(who) + ": A outside [1, 64]");
+    if (begin_id < 0 || begin_id + (int64_t)A > seq_len)
+        return fail(IPX_ERR_ARG, std::string(who) + ": aspect tokens outside the sequence");
+    if (n < 0 || n > 0x7fffffff) return fail(IPX_ERR_ARG, std::string(who) + ": n outside [0, 2^31)");
+    if (n == 0) return 0;
+    if (!hidden || !W || !b) return fail(IPX_ERR_ARG, std::string(who) + ": null pointer");
+    IPX_HIP(hipSetDevice(ix->device));
+    const int d = ix->d;
+    const hipMemcpyKind in = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    // keep [CLS] and the A aspect rows of every sequence: [n][1 + A][d]
+    const size_t row = (size_t)d * sizeof(float), kept = (size_t)(1 + A) * row, pitch = (size_t)seq_len * row;
+    if (int rc = ix->poolH.ensure((size_t)n * kept)) return rc;
+    if (int rc = ix->poolW.ensure((size_t)A * row + (size_t)A * sizeof(float) + (size_t)n * A * sizeof(float))) return rc;
+    if (int rc = ix->poolQ.ensure((size_t)n * row)) return rc;
+    IPX_HIP(hipMemcpy2DAsync(ix->poolH.p, kept, hidden, pitch, row, (size_t)n, in, st));
+    IPX_HIP(hipMemcpy2DAsync((char*)ix->poolH.p + row, kept, (const char*)hidden + (size_t)begin_id * row, pitch,
+                             (size_t)A * row, (size_t)n, in, st));
+    float* dW = (float*)ix->poolW.p;
+    float* db = dW + (size_t)A * d;
+    float* datt = db + A;
+    IPX_HIP(hipMemcpyAsync(dW, W, (size_t)A * row, in, st));
+    IPX_HIP(hipMemcpyAsync(db, b, (size_t)A * sizeof(float), in, st));
+    hipLaunchKernelGGL(ipx::mural_pool_kernel, dim3((unsigned)n), dim3(256), 0, st, (const float*)ix->poolH.p, dW, db, A, n,
+                       d, (float*)ix->poolQ.p, datt);
+    IPX_HIP(hipGetLastError());
+    if (out_att)
+        IPX_HIP(hipMemcpyAsync(out_att, datt, (size_t)n * A * sizeof(float),
+                               on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+int ipx_pool(ipx_index* ix, const float* hidden, int64_t seq_len, const float* W, const float* b, int A, int begin_id,
+             int64_t n, float* out_rep, float* out_att, int on_device, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n > 0 && !out_rep) return fail(IPX_ERR_ARG, "pool: null pointer");
+    if (int rc = pool_impl(ix, "pool", hidden, seq_len, W, b, A, begin_id, n, out_att, on_device, st)) return rc;
+    if (n == 0) return 0;
+    IPX_HIP(hipMemcpyAsync(out_rep, ix->poolQ.p, (size_t)n * ix->d * sizeof(float),
+                           on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    if (!on_device) IPX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int ipx_add_pooled(ipx_index* ix, const float* hidden, int64_t seq_len, const float* W, const float* b, int A,
+                   int begin_id, int64_t n, int on_device, void* stream) {
+    if (int rc = pool_impl(ix, "add_pooled", hidden, seq_len, W, b, A, begin_id, n, nullptr, on_device, (hipStream_t)stream))
+        return rc;
+    if (n == 0) return 0;
+    if (int rc = ipx_add(ix, ix->poolQ.p, n, IPX_F32, 1, stream)) return rc;
+    if (!on_device) IPX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int ipx_search_pooled(ipx_index* ix, const float* hidden, int64_t seq_len, const float* W, const float* b, int A,
+                      int begin_id, int64_t nq, int k, float* out_D, int64_t* out_I, float* out_att, int on_device,
+                      void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (k <= 0 || k > IPX_MAX_K) return fail(IPX_ERR_ARG, "search_pooled: k outside [1, IPX_MAX_K]");
+    if (nq > 0 && (!out_D || !out_I)) return fail(IPX_ERR_ARG, "search_pooled: null pointer");
+    if (int rc = pool_impl(ix, "search_pooled", hidden, seq_len, W, b, A, begin_id, nq, out_att, on_device, st)) return rc;
+    if (nq == 0) return 0;
+    if (on_device) return search_impl(ix, (const float*)ix->poolQ.p, nullptr, 0, 0, nq, k, out_D, out_I, 1, stream);
+    // host outputs: search on the pooled queries (already on the device), then copy the lists back
+    const size_t nout = (size_t)nq * k;
+    if (int rc = ix->outD.ensure(nout * sizeof(float))) return rc;
+    if (int rc = ix->outI.ensure(nout * sizeof(int64_t))) return rc;
+    if (int rc = search_impl(ix, (const float*)ix->poolQ.p, nullptr, 0, 0, nq, k, (float*)ix->outD.p, (int64_t*)ix->outI.p, 1,
+                             stream))
+        return rc;
+    IPX_HIP(hipMemcpyAsync(out_D, ix->outD.p, nout * sizeof(float), hipMemcpyDeviceToHost, st));
+    IPX_HIP(hipMemcpyAsync(out_I, ix->outI.p, nout * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    return ipx_check(ix, stream);
 }
 
 int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in, int k_out, float* out_D,

@@ -59,6 +59,44 @@ fuse_aspect_kernel(const float* __restrict__ src, const float* __restrict__ w, i
     dst[gid] = v;
 }
 
+// MURAL query / document pooler (MULGRAIN_Pooler.forward, 'att' type, mul_grain.py:97-132):
+//   logits = W h[0] + b;  rep = sum_a softmax(logits)_a * h[begin_id + a]
+// h: [n][rows_kept][d] — row 0 is the [CLS] hidden state, rows 1..A the aspect tokens (the host
+// passes only these rows of the encoder output). One workgroup per vector; the weighted sum runs
+// as the same fmaf chain over the aspects as fuse_aspect_kernel.
+__global__ void __launch_bounds__(256)
+mural_pool_kernel(const float* __restrict__ h, const float* __restrict__ W, const float* __restrict__ b,
+                  int A, int64_t n, int d, float* __restrict__ dst, float* __restrict__ att_out) {
+    __shared__ float s_logit[64];
+    __shared__ float s_w[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r = blockIdx.x;
+    const float* cls = h + r * (int64_t)(1 + A) * d;
+    for (int a = wave; a < A; a += 4) {
+        float acc = 0.f;
+        for (int e = lane; e < d; e += 64) acc = fmaf(W[(int64_t)a * d + e], cls[e], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) s_logit[a] = acc + b[a];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float mx = -INFINITY, den = 0.f;
+        for (int a = 0; a < A; ++a) mx = fmaxf(mx, s_logit[a]);
+        for (int a = 0; a < A; ++a) den += expf(s_logit[a] - mx);
+        for (int a = 0; a < A; ++a) {
+            s_w[a] = expf(s_logit[a] - mx) / den;
+            if (att_out) att_out[r * A + a] = s_w[a];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < d; e += 256) {
+        float v = 0.f;
+        for (int a = 0; a < A; ++a) v = fmaf(s_w[a], cls[(int64_t)(1 + a) * d + e], v);
+        dst[r * (int64_t)d + e] = v;
+    }
+}
+
 // row-major [n, d] (f32 / f16 / bf16) -> tiled, padded, swizzled bf16 (round to nearest even).
 // One thread per (row, 16-byte chunk of 8 bf16). parts == 2 (queries only) also writes the
 // residual lo = bf16(x - hi) as a second block behind each stage: x ~ hi + lo to 16 bits.

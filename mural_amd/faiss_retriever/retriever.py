@@ -147,6 +147,45 @@ class FlatIPIndex:
                                        C.c_void_p(I.ctypes.data), 0, None))
         return D, I
 
+    # ---- MURAL pooler on the device (MULGRAIN_Pooler.forward 'att', modeling/mul_grain.py:97-132) ----
+    def _pool_args(self, hidden, weight, bias, begin_id):
+        hidden = np.ascontiguousarray(hidden, dtype="float32")
+        weight = np.ascontiguousarray(weight, dtype="float32")
+        bias = np.ascontiguousarray(bias, dtype="float32")
+        assert hidden.ndim == 3 and weight.ndim == 2
+        n, seq_len, d = hidden.shape
+        A = weight.shape[0]
+        assert d == self.d and weight.shape == (A, d) and bias.shape == (A,)
+        keep = (hidden, weight, bias)
+        return keep, (C.c_void_p(hidden.ctypes.data), seq_len, C.c_void_p(weight.ctypes.data),
+                      C.c_void_p(bias.ctypes.data), A, int(begin_id), n), n, A
+
+    def pool(self, hidden, weight, bias, begin_id=1):
+        """hidden [n, seq_len, d] last hidden states, weight [A, d] / bias [A] = cls_linear_q (= cls_linear_d
+        when tied) of pooler.pt; aspect tokens at begin_id .. begin_id+A-1 (src/pretrain_finetune1.sh:22-23:
+        A=3, begin_id=1). Returns (rep [n, d], att [n, A]) like the reference's (res, _, q_att)."""
+        keep, args, n, A = self._pool_args(hidden, weight, bias, begin_id)
+        rep = np.empty((n, self.d), dtype=np.float32)
+        att = np.empty((n, A), dtype=np.float32)
+        _lib.check(_lib.lib().ipx_pool(self._h, *args, C.c_void_p(rep.ctypes.data), C.c_void_p(att.ctypes.data), 0, None))
+        return rep, att
+
+    def add_pooled(self, hidden, weight, bias, begin_id=1):
+        """Pool passages' hidden states and append the representations (encode + index without the pickles)."""
+        keep, args, n, A = self._pool_args(hidden, weight, bias, begin_id)
+        _lib.check(_lib.lib().ipx_add_pooled(self._h, *args, 0, None))
+
+    def search_pooled(self, hidden, weight, bias, k, begin_id=1, return_att=False):
+        """Pool queries' hidden states and search, one call."""
+        keep, args, n, A = self._pool_args(hidden, weight, bias, begin_id)
+        assert k > 0
+        D = np.empty((n, k), dtype=np.float32)
+        I = np.empty((n, k), dtype=np.int64)
+        att = np.empty((n, A), dtype=np.float32)
+        _lib.check(_lib.lib().ipx_search_pooled(self._h, *args, k, C.c_void_p(D.ctypes.data), C.c_void_p(I.ctypes.data),
+                                                C.c_void_p(att.ctypes.data), 0, None))
+        return (D, I, att) if return_att else (D, I)
+
     # bench / profiling helpers
     def set_param(self, name, value):
         _lib.check(_lib.lib().ipx_set_param(self._h, name.encode(), int(value)))

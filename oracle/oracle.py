@@ -10,6 +10,8 @@ the published faiss 1.7.2 algorithm for exactly the calls the reference makes:
 
   FlatIPOracle        faiss.IndexFlatIP + its numpy wrapper      retriever.py:12,16,19
   ResultHeapOracle    faiss.ResultHeap (python class)             reducer.py:15-18
+  mural_pool_att      MULGRAIN_Pooler.forward, 'att' pooling      modeling/mul_grain.py:97-132
+                      (this one IS pinned: tests/golden/pooler_att.npz comes from the reference module)
 
 The heap code is C (flat_ip_oracle.c, built by `make -C oracle`); the blocked sgemm that
 faiss delegates to BLAS is numpy's matmul (OpenBLAS here).
@@ -140,6 +142,22 @@ def combine_results(results):
 
 
 # ---- references that are not faiss restatements --------------------------------------------
+
+def mural_pool_att(hidden, W, b, begin_id=1):
+    """MULGRAIN_Pooler.forward, 'att' pooling (modeling/mul_grain.py:97-110 for queries, :117-132 for
+    passages — the same arithmetic): att = softmax(h[:,0] W^T + b); rep = att @ h[:, begin:begin+A].
+    Pinned by tests/golden/pooler_att.npz, which the reference module itself produced."""
+    hidden = np.asarray(hidden, dtype=np.float32)
+    W = np.asarray(W, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
+    A = W.shape[0]
+    logits = hidden[:, 0] @ W.T + b
+    e = np.exp(logits - logits.max(axis=1, keepdims=True))
+    att = (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+    asp = hidden[:, begin_id:begin_id + A]
+    rep = np.einsum("na,nad->nd", att, asp).astype(np.float32)
+    return rep, att
+
 
 def exact_topk_f64(Q, X, k):
     """Exact scores in float64; order (score desc, row asc). Returns (D64 [nq,kk], I [nq,kk])."""

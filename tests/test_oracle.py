@@ -121,3 +121,17 @@ def test_mfma_order_scores_close_to_exact():
                              else np.float32(np.float64(X2[j, g + e]) * np.float64(Q2[q, g + e]) + np.float64(acc[q, j]))
                              for j in range(64)] for q in range(4)], dtype=np.float32)
     assert np.array_equal(acc, O.scores_mfma_order(Q2, X2))
+
+
+# ---- MURAL pooler: this restatement IS pinned, by outputs of the reference's own module -------------
+@pytest.mark.parametrize("tag", ["small", "bert", "wide"])
+def test_mural_pool_matches_reference_module_outputs(tag):
+    import os
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "pooler_att.npz"))
+    W, b, begin = g[f"{tag}_W"], g[f"{tag}_b"], int(g[f"{tag}_begin"])
+    for side in "qp":
+        rep, att = O.mural_pool_att(g[f"{tag}_h{side}"], W, b, begin)
+        assert np.allclose(att, g[f"{tag}_{side}_att"], rtol=1e-5, atol=1e-7)
+        assert np.allclose(rep, g[f"{tag}_{side}_rep"], rtol=1e-5, atol=1e-6)
+        assert np.allclose(att.sum(1), 1.0, atol=1e-6)
