@@ -5,6 +5,7 @@
 // in include/ipx.h. No CPU fallback: without a HIP device every compute call fails with
 // IPX_ERR_HIP.
 #include "ipx_bf16_kernels.h"
+#include "ipx_f32_small_kernels.h"
 #include "../../include/ipx.h"
 
 #include <algorithm>
@@ -89,6 +90,7 @@ struct ipx_index {
     int max_splits = 0;      // 0 = automatic
     int force_kc = 0;        // 0 = automatic candidate count
     int query_parts = 0;     // 0 = automatic; 1 / 2 bf16 parts per query in the bf16 scan
+    int small_f32_limit = 192;     // fp32 scans of up to this many queries take scan_f32_small_kernel
     bool no_small_batch = false;   // diagnostic: always use the 256-query bf16 scan variant
     bool force_f32_scan = false;   // storage 1: use the fp32 scan although a bf16 copy exists
     size_t tile_bytes() const { return (size_t)nks * ipx::STAGE_A_BYTES; }
@@ -207,10 +209,125 @@ int dtype_size(int dtype) { return dtype == IPX_F32 ? 4 : 2; }
 
 struct Geometry { int nqb, ntiles, S, R, G, cap; };
 
+// fp32 scan of a small batch (scan_f32_small_kernel: 32 or 64 queries per workgroup, one workgroup
+// per CU): pack -> scan -> merge. Same scores, bit for bit, as scan_f32_path.
+int scan_f32_small_path(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
+                        float* dD, int64_t* dI, hipStream_t st, bool primary) {
+    const bool record = primary && ix->timing;
+    const int d = ix->d, nks = ix->nks;
+    const int64_t N = ix->ntotal;
+    const size_t nout = (size_t)nq * k;
+    const int qt = nq <= 32 ? 1 : 2;
+    const int bq = 32 * qt;
+    const int nqb = (int)((nq + bq - 1) / bq);
+    const int ntiles = (int)((N + ipx::BD - 1) / ipx::BD);
+    hipDeviceProp_t prop;
+    IPX_HIP(hipGetDeviceProperties(&prop, ix->device));
+    const int resident = 2 * prop.multiProcessorCount;      // two 512-thread workgroups per CU
+    const int npairs = (ntiles + 1) / 2;                    // the kernel steps through pairs of corpus tiles
+    int S = std::max(1, resident / nqb);
+    if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
+    const int R = std::max(2, std::min(32, npairs / (S * 64)));
+    const int nruns = (npairs + R - 1) / R;
+    S = std::min(S, nruns);
+    const int G = nqb * S;
+    // queue: k survivors of a compaction + 2 steps (4 tiles) of appends before the next one runs + room to fill
+    const int cap = next_pow2(k + 4 * ipx::BD + k / 2);
+    const int ring = qt == 1 ? ipx::SCfg<1>::RING : ipx::SCfg<2>::RING;
+    const int nsortwaves = std::max(1, std::min(8, ring / (cap * 8)));
+    const int stage_b = bq * 64;
+
+    if (int rc = ix->Qp.ensure((size_t)nqb * nks * stage_b)) return rc;
+    if (int rc = ix->cand.ensure((size_t)G * bq * cap * sizeof(uint64_t))) return rc;
+    if (int rc = ix->err.ensure(256)) return rc;
+    if (S > 1) {
+        if (int rc = ix->partD.ensure(nout * S * sizeof(float))) return rc;
+        if (int rc = ix->partI.ensure(nout * S * sizeof(int64_t))) return rc;
+        if (int rc = ix->flags.ensure((size_t)nq * sizeof(int))) return rc;
+    }
+    const size_t ctr_bytes = ((size_t)nqb * sizeof(uint32_t) + 255) / 256 * 256;
+    const size_t pub_bytes = ctr_bytes + (size_t)G * bq * sizeof(uint32_t);
+    if (int rc = ix->pub.ensure(pub_bytes)) return rc;
+    IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
+
+    if (record) IPX_HIP(hipEventRecord(ix->ev[0], st));
+    if (int rc = launch_pack(dq, IPX_F32, nq, (int64_t)nqb * bq, d, (float*)ix->Qp.p, 0, bq, nks, dw, A, logits, st))
+        return rc;
+    if (record) IPX_HIP(hipEventRecord(ix->ev[1], st));
+
+    ipx::ScanParams p;
+    p.Xp = ix->Xp;
+    p.Qp = (const float*)ix->Qp.p;
+    p.cand = (uint64_t*)ix->cand.p;
+    p.outD = S > 1 ? (float*)ix->partD.p : dD;
+    p.outI = S > 1 ? (int64_t*)ix->partI.p : dI;
+    p.err = (int*)ix->err.p;
+    p.run_ctr = (uint32_t*)ix->pub.p;
+    p.pub = (uint32_t*)((char*)ix->pub.p + ctr_bytes);
+    p.run_tiles = R;
+    p.r = (k + S - 1) / S;
+    p.trace = nullptr;
+    if (ix->trace_on) {
+        if (int rc = ix->trace.ensure((size_t)G * 20 * sizeof(uint64_t))) return rc;
+        p.trace = (uint64_t*)ix->trace.p;
+    }
+    p.N = N;
+    p.id_base = ix->id_base;
+    p.nq = (int)nq;
+    p.nks = nks;
+    p.k = k;
+    p.cap = cap;
+    p.S = S;
+    p.ntiles = ntiles;
+    const int lds = std::max(ring, nsortwaves * cap * 8) + ipx::LDS_STATE_BYTES;
+    {
+        void (*kern)(const ipx::ScanParams, const int) = qt == 1 ? ipx::scan_f32_small_kernel<1> : ipx::scan_f32_small_kernel<2>;
+        IPX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(kern, dim3(G), dim3(512), lds, st, p, nsortwaves);
+    }
+    IPX_HIP(hipGetLastError());
+    if (record) IPX_HIP(hipEventRecord(ix->ev[2], st));
+
+    if (S > 1) {
+        const int P = next_pow2(k);
+        const int mlds = P * 24;
+        if (mlds > 64 * 1024)
+            IPX_HIP(hipFuncSetAttribute((const void*)ipx::merge_topk_kernel,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, mlds));
+        // many short lists: cut by the union bound and sort once; the fold kernel then only serves
+        // queries whose pool overflowed
+        const int* todo = nullptr;
+        if (S >= 16) {
+            hipLaunchKernelGGL(ipx::merge_pool_kernel, dim3((unsigned)nq), dim3(256), 0, st, (const float*)ix->partD.p,
+                               (const int64_t*)ix->partI.p, S, k, k, (int64_t)k, (int64_t)S * k, dD, dI, (int*)ix->flags.p);
+            IPX_HIP(hipGetLastError());
+            todo = (const int*)ix->flags.p;
+        }
+        hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st,
+                           (const float*)ix->partD.p, (const int64_t*)ix->partI.p, S, nq, k, k, P, 1,
+                           (int64_t)k, (int64_t)S * k, dD, dI, todo);
+        IPX_HIP(hipGetLastError());
+        if (record) {
+            IPX_HIP(hipEventRecord(ix->ev[3], st));
+            ix->ev_merge = true;
+        }
+    }
+    if (primary) {
+        ix->ev_valid = ix->timing;
+        ix->last_wgs = G;
+        ix->last_S = S;
+        ix->last_cap = cap;
+    }
+    return 0;
+}
+
 // fp32 scan of nq row-major fp32 queries already on the device (A > 0: aspect embeddings + weights,
 // fused by the pack kernel): pack -> scan -> merge. Results (device) in dD / dI.
 int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
                   float* dD, int64_t* dI, hipStream_t st, bool primary) {
+    // up to 192 queries: the 32 / 64-query tile does a fraction of the 256-query tile's matrix work
+    if (nq <= ix->small_f32_limit && !ix->no_small_batch)
+        return scan_f32_small_path(ix, dq, dw, A, logits, nq, k, dD, dI, st, primary);
     const bool record = primary && ix->timing;
     const int d = ix->d, nks = ix->nks;
     const int64_t N = ix->ntotal;
@@ -919,6 +1036,10 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
             return fail(IPX_ERR_STATE, "set_param: storage can only be chosen while the index is empty and unreserved");
         if (value != 0 && ix->d > 8192) return fail(IPX_ERR_ARG, "set_param: bf16 storage needs d <= 8192");
         ix->storage = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "small_f32_limit")) {
+        ix->small_f32_limit = (int)value;
         return 0;
     }
     if (!strcmp(name, "no_small_batch")) {

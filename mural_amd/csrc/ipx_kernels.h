@@ -762,13 +762,15 @@ merge_topk_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, in
 }
 
 // Merge of S SORTED lists per query, S large (the scan's per-split lists when few queries spread
-// over every CU: S = 256 lists for a batch of <= 64 queries). Folding them one by one costs S
-// dependent merge rounds; this kernel cuts first: with r = ceil(k_out / S), every list holds r
-// entries at or above its own r-th entry, so v = the smallest of those r-th entries has at least
-// S*r >= k_out entries at or above it — nothing below v can be in the result. One thread per list
-// walks its head while entries are >= v into an LDS pool (lists are sorted: it stops at the first
-// smaller entry), the pool is sorted once, order (score desc, id asc). A pool overflow (masses of
-// ties) sets todo[q] = 1 and merge_topk_kernel folds that query the slow way.
+// over every CU: S = 256 or 512 lists for a batch of <= 64 queries). Folding them one by one costs
+// S dependent merge rounds; this kernel cuts first. Take the first m entries of every list
+// (S*m <= MERGE_POOL values, m >= ceil(k_out / S) so there are at least k_out of them unless the
+// lists are short): the k_out-th largest of these values, v, is the score of an actual entry with
+// at least k_out entries at or above it — nothing below v can be in the result. (With m = 1 this
+// is "the k-th best list head".) One thread per list then walks its head while entries are >= v
+// into an LDS pool (lists are sorted: it stops at the first smaller entry), the pool is sorted
+// once, order (score desc, id asc). A pool overflow (masses of ties) sets todo[q] = 1 and
+// merge_topk_kernel folds that query the slow way.
 constexpr int MERGE_POOL = 4096;
 
 __global__ void __launch_bounds__(256)
@@ -779,22 +781,41 @@ merge_pool_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, in
     __shared__ uint32_t pos_[MERGE_POOL];
     __shared__ uint32_t s_v;
     __shared__ int s_n;
+    __shared__ int s_cnt[3];
     const int tid = threadIdx.x;
     const int64_t q = blockIdx.x;
     const int r = (k_out + S - 1) / S;
-    if (tid == 0) { s_v = 0xffffffffu; s_n = 0; }
-    __syncthreads();
-    // v: the smallest r-th entry over the lists (0 = some list has fewer than r entries: no cut)
-    uint32_t mine = 0xffffffffu;
-    for (int s = tid; s < S; s += 256) {
-        uint32_t o = 0;
-        if (r <= k_in) {
-            const float sc = D[s * shard_stride + q * query_stride + (r - 1)];
-            if (sc > -FLT_MAX) o = f32_ordered(sc);
+    int m = MERGE_POOL / S;
+    m = m < r ? r : m;
+    m = m > k_in ? k_in : m;
+    if (tid == 0) { s_v = 0; s_n = 0; s_cnt[0] = s_cnt[1] = s_cnt[2] = 0; }
+    if ((int64_t)S * m <= MERGE_POOL && r <= k_in) {
+        // the sample: first m entries of each list, as ordered bits (0 = empty slot), in pos_
+        const int nv = S * m;
+        for (int e = tid; e < nv; e += 256) {
+            const int s = e / m, i = e - s * m;
+            const float sc = D[s * shard_stride + q * query_stride + i];
+            pos_[e] = sc > -FLT_MAX ? f32_ordered(sc) : 0u;
         }
-        mine = o < mine ? o : mine;
+        __syncthreads();
+        // v = the k_out-th largest sample value, bit by bit from the top (0 if there are fewer)
+        // (three counters in rotation: one barrier per round — the counter of the round after
+        // next is cleared while this round's is read)
+        uint32_t v = 0;
+        for (int b = 31, rr = 0; b >= 0; --b, rr = rr == 2 ? 0 : rr + 1) {
+            const uint32_t cand = v | (1u << b);
+            int c = 0;
+            for (int e = tid; e < nv; e += 256) c += pos_[e] >= cand ? 1 : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+            if ((tid & 63) == 0 && c) atomicAdd(&s_cnt[rr], c);
+            if (tid == 0) s_cnt[rr == 2 ? 0 : rr + 1] = 0;
+            __syncthreads();
+            if (s_cnt[rr] >= k_out) v = cand;
+        }
+        if (tid == 0) s_v = v;
+        __syncthreads();
     }
-    atomicMin(&s_v, mine);
     __syncthreads();
     const uint32_t v = s_v;
     for (int s = tid; s < S; s += 256) {
