@@ -199,6 +199,20 @@ def main():
                                        "unit": "GB/s", "frac": bytes_scan / (sc3a * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                        "kernel": "scan_bf16_kernel<1>"}})
         extra["small_batch_bf16_copy"] = small
+        # the same batches against the fp32 rows themselves (what a storage-0 index serves)
+        ix.set_param("f32_scan", 1)
+        small32 = []
+        for bnq in (1, 16, 64):
+            el3, sc3, _, _ = timed(Q[:bnq].contiguous(), 20, 3)
+            sc3a = sum(sc3) / len(sc3)
+            bytes_scan = (hi - lo) * d * 4
+            small32.append({"queries": bnq, "ms_per_search": el3 * 1e3 / 20, "queries_per_s": bnq / (el3 / 20),
+                            "scan_ms": sc3a, "corpus_bytes_streamed": bytes_scan,
+                            "roofline": {"bound": "hbm", "achieved": bytes_scan / (sc3a * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                         "unit": "GB/s", "frac": bytes_scan / (sc3a * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                         "kernel": "scan_f32_small_kernel<%d>" % (1 if bnq <= 32 else 2)}})
+        ix.set_param("f32_scan", 0)
+        extra["small_batch_f32_rows"] = small32
 
     if rank == 0:
         scan_avg = sum(scan_ms) / len(scan_ms)
