@@ -189,7 +189,11 @@ template <int QW, int QP> struct HCfg {
     static constexpr int STAGE_B = PART_B * QP;
     static constexpr int STAGE = HSTAGE_A + STAGE_B;     // 32 / 48 KiB (QW 4), 20 / 24 KiB (QW 1)
     static constexpr int NBUF = QW == 4 ? (QP == 1 ? 4 : 3) : 6;      // LDS stage ring (<= 144 KiB)
+#ifdef IPX_ABL_NO_B_COPY      // diagnostic build: the query stage is never copied (results are meaningless)
+    static constexpr int LOADS = 2;
+#else
     static constexpr int LOADS = 2 + (QW == 4 ? 2 * QP : 1);          // LDS-DMA pieces per thread per stage
+#endif
     static constexpr int RING = NBUF * STAGE;
 };
 
@@ -214,7 +218,9 @@ struct StagePieces {
     // piece i of HCfg::LOADS: 0, 1 = the A rounds; 2.. = the B rounds (8 KiB apart)
     __device__ __forceinline__ void issue(int i) const {
         if (i < 2) IPX_GLDS(ga + i * 8192, la + i * 8192);
+#ifndef IPX_ABL_NO_B_COPY
         else IPX_GLDS(gb + (i - 2) * 8192, lb + (i - 2) * 8192);
+#endif
     }
 };
 

@@ -17,9 +17,12 @@ for lo in range(0, rows, 500000):
     ix.add(x)
 del x
 ix.set_timing(True)
+if os.environ.get('MAX_SPLITS'):
+    ix.set_param('max_splits', int(os.environ['MAX_SPLITS']))
+NQS = [int(a) for a in os.environ.get('NQS', '1,8,32,33,64,65,128,192,256').split(',')]
 gb = rows * d * 4 / 1e9
 for k in ks:
-    for nq in (1, 8, 32, 33, 64, 65, 128, 192, 256):
+    for nq in NQS:
         Q = torch.randn((nq, d), generator=g, device=dev)
         ix.set_param("no_small_batch", 1)
         D0, I0 = ix.search_device(Q, k)
