@@ -9,6 +9,8 @@ are a vectorised numpy gather and one C call.
 import ctypes as C
 import glob
 import logging
+import mmap
+import os
 import pickle
 from argparse import ArgumentParser
 from itertools import chain
@@ -97,12 +99,74 @@ def write_ranking(corpus_indices, corpus_scores, q_lookup, ranking_save_file):
         C.c_void_p(scores.ctypes.data), nq, k))
 
 
+class _PayloadSkippingReader:
+    """File wrapper for pickle.Unpickler that does not read large byte payloads: a request of
+    >= `threshold` bytes (the raw data of an ndarray: pickle writes it unframed and the C unpickler
+    asks for it with one readinto() straight into the new bytes object) is recorded as
+    (offset, size) and skipped with a seek — the destination stays untouched memory that is never
+    looked at. Everything else (opcodes, the id list) is read normally. No peek(): the unpickler
+    then never buffers ahead, so offsets are exact."""
+
+    def __init__(self, f, threshold):
+        self._f, self._threshold, self.skipped = f, threshold, []
+
+    def read(self, n=-1):
+        if n is not None and n >= self._threshold:
+            self.skipped.append(None)           # a large read that cannot be skipped: give up the fast path
+        return self._f.read(n)
+
+    def readline(self):
+        return self._f.readline()
+
+    def readinto(self, b):
+        n = len(b)
+        if n >= self._threshold:
+            self.skipped.append((self._f.tell(), n))
+            self._f.seek(n, os.SEEK_CUR)
+            return n
+        return self._f.readinto(b)
+
+
+def _pickle_load_mapped(path, threshold=1 << 20):
+    """(reps, lookup, ...) with reps as a read-only np.memmap of the pickle file itself, or None when
+    the file does not have the expected shape (then the caller unpickles the ordinary way). The page
+    cache is the only host copy of the rows: ipx_add's staging threads read them from the mapping."""
+    with open(path, 'rb') as f:
+        rd = _PayloadSkippingReader(f, threshold)
+        try:
+            payload = pickle.Unpickler(rd).load()
+        except Exception:
+            return None
+        size = f.seek(0, os.SEEK_END)
+    if not isinstance(payload, tuple) or not payload or len(rd.skipped) != 1 or rd.skipped[0] is None:
+        return None
+    reps = payload[0]
+    offset, nbytes = rd.skipped[0]
+    if not (isinstance(reps, np.ndarray) and reps.dtype.kind == 'f' and reps.dtype.isnative and reps.ndim == 2
+            and reps.flags.c_contiguous and reps.nbytes == nbytes and offset + nbytes <= size):
+        return None
+    shape, dtype = reps.shape, reps.dtype
+    del reps                                    # its pages were never touched
+    mapped = np.memmap(path, dtype=dtype, mode='r', offset=offset, shape=shape)
+    try:
+        mapped._mmap.madvise(mmap.MADV_SEQUENTIAL)
+    except (AttributeError, OSError, ValueError):
+        pass
+    return (mapped,) + tuple(payload[1:])
+
+
 def pickle_load(path):
     """__main__.py:41-48: a pickle holding (reps, lookup) or (reps, lookup, _, _); reps may be
     an ndarray (f16 / f32) or a list of rows (jax_encode.py:112-114) and comes back as an
-    ndarray. Any other tuple length fails the way the reference does (UnboundLocalError)."""
-    with open(path, 'rb') as f:
-        payload = pickle.load(f)
+    ndarray. Any other tuple length fails the way the reference does (UnboundLocalError).
+
+    A float ndarray of >= 1 MiB is not read at all here: it comes back as a read-only mapping of
+    the file (IPX_MMAP_LOAD=0 turns this off), so a 27 GB shard costs no host copy before ipx_add
+    streams it to the GPU. The reference makes three (unpickle, np.array, faiss add)."""
+    payload = _pickle_load_mapped(path) if os.environ.get('IPX_MMAP_LOAD', '1') != '0' else None
+    if payload is None:
+        with open(path, 'rb') as f:
+            payload = pickle.load(f)
     if len(payload) not in (2, 4):
         raise UnboundLocalError("local variable 'reps' referenced before assignment")
     # the reference copies here (np.array); an unpickled ndarray is already private to this call,

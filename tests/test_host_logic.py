@@ -221,3 +221,39 @@ def test_product_code_never_touches_the_oracle():
                 if fn.endswith((".py", ".hip", ".h", ".cpp")):
                     txt = open(os.path.join(dp, fn), errors="replace").read()
                     assert "oracle" not in txt.replace("oracle-engine", ""), os.path.join(dp, fn)
+
+
+# ---- index load path: mapped pickle payload ---------------------------------
+def test_pickle_load_maps_large_payloads_and_equals_plain_unpickling(tmp_path, monkeypatch):
+    import pickle
+    from mural_amd.faiss_retriever import __main__ as drv
+    rng = np.random.default_rng(5)
+    big32 = rng.standard_normal((3000, 128), dtype=np.float32)           # 1.5 MB: above the 1 MiB threshold
+    cases = {
+        "f32": ((big32, [str(i) for i in range(3000)]), True),
+        "f16_4tuple": ((big32.astype(np.float16).repeat(2, axis=0), list(range(6000)), None, {"x": 1}), True),
+        "small": ((big32[:10], list(range(10))), False),
+        "list_of_rows": (([r for r in big32[:7]], list(range(7))), False),
+        "fortran": ((np.asfortranarray(big32), list(range(3000))), False),
+        "two_payloads": ((big32, big32 + 1), False),
+    }
+    for name, (obj, mapped) in cases.items():
+        for proto in (2, 4, 5):
+            path = tmp_path / f"{name}_{proto}.pkl"
+            with open(path, "wb") as f:
+                pickle.dump(obj, f, protocol=proto)
+            monkeypatch.setenv("IPX_MMAP_LOAD", "0")
+            a = drv.pickle_load(str(path))
+            monkeypatch.setenv("IPX_MMAP_LOAD", "1")
+            b = drv.pickle_load(str(path))
+            assert isinstance(b[0], np.ndarray) and b[0].dtype == a[0].dtype and b[0].shape == a[0].shape
+            assert np.array_equal(a[0], b[0]), (name, proto)
+            if isinstance(a[1], np.ndarray):
+                assert np.array_equal(a[1], b[1])
+            else:
+                assert a[1] == b[1]
+            assert isinstance(b[0], np.memmap) == (mapped and proto >= 3), (name, proto)
+    with open(tmp_path / "bad.pkl", "wb") as f:
+        pickle.dump((big32, [], 3), f)
+    with pytest.raises(UnboundLocalError):
+        drv.pickle_load(str(tmp_path / "bad.pkl"))
