@@ -10,6 +10,7 @@ import ctypes as C
 import glob
 import logging
 import mmap
+import operator
 import os
 import pickle
 from argparse import ArgumentParser
@@ -40,13 +41,15 @@ def _lookup_strings(p_lookup, all_indices):
         return np.array([[str(p_lookup[x]) for x in row] for row in all_indices])
     if (flat >= n).any() or (flat < -n).any():
         raise IndexError("list index out of range")
-    if flat.size < n:
-        uniq, inv = np.unique(flat, return_inverse=True)
-        table = np.array([str(p_lookup[int(x)]) for x in uniq])
-        out = table[inv.reshape(-1)].reshape(all_indices.shape)
-    else:
-        table = np.array([str(x) for x in p_lookup])
-        out = table[flat].reshape(all_indices.shape)
+    flat = np.where(flat < 0, flat + n, flat)
+    # the distinct rows hit, by a mark-and-scan over the lookup's length (no sort of nq*k ids)
+    hit = np.zeros(n, dtype=bool)
+    hit[flat] = True
+    uniq = np.flatnonzero(hit)
+    got = operator.itemgetter(*uniq.tolist())(p_lookup) if uniq.size > 1 else (p_lookup[int(uniq[0])],)
+    table = np.array(got) if all(type(x) is str for x in got) else np.array([str(x) for x in got])
+    slot = np.cumsum(hit, dtype=np.int64) - 1
+    out = table[slot[flat]].reshape(all_indices.shape)
     # np.array(list of str lists) sizes the dtype to the longest string present
     width = max(int(np.char.str_len(out).max()), 1)
     return out.astype(f"<U{width}")
