@@ -114,13 +114,15 @@ int grow_corpus(ipx_index* ix, int64_t need_tiles, hipStream_t st) {
         return fail(IPX_ERR_NOMEM, "hipMalloc(corpus, " + std::to_string(nbytes) + " bytes): " + hipGetErrorString(e));
     const size_t old_bytes = (size_t)ix->cap_tiles * ix->tile_bytes();
     const size_t new_bytes = (size_t)new_tiles * ix->tile_bytes();
-    if (old_bytes) IPX_HIP(hipMemcpyAsync(nb, ix->Xp, old_bytes, hipMemcpyDeviceToDevice, st));
+    hipError_t ce = old_bytes ? hipMemcpyAsync(nb, ix->Xp, old_bytes, hipMemcpyDeviceToDevice, st) : hipSuccess;
     // rows of a partly filled tile must read as zeros
-    IPX_HIP(hipMemsetAsync((char*)nb + old_bytes, 0, new_bytes - old_bytes, st));
-    if (ix->Xp) {
-        IPX_HIP(hipStreamSynchronize(st));
-        (void)hipFree(ix->Xp);
+    if (ce == hipSuccess) ce = hipMemsetAsync((char*)nb + old_bytes, 0, new_bytes - old_bytes, st);
+    if (ce == hipSuccess && ix->Xp) ce = hipStreamSynchronize(st);
+    if (ce != hipSuccess) {
+        (void)hipFree(nb);
+        return fail(IPX_ERR_HIP, std::string("grow corpus: ") + hipGetErrorString(ce));
     }
+    if (ix->Xp) (void)hipFree(ix->Xp);
     ix->Xp = nb;
     ix->cap_tiles = new_tiles;
     return 0;
@@ -140,12 +142,14 @@ int grow_corpus_h(ipx_index* ix, int64_t need_tiles, hipStream_t st) {
         return fail(IPX_ERR_NOMEM, std::string("hipMalloc(bf16 corpus): ") + hipGetErrorString(e));
     const size_t old_bytes = (size_t)ix->cap_tiles_h * ix->tile_bytes_h();
     const size_t new_bytes = (size_t)new_tiles * ix->tile_bytes_h();
-    if (old_bytes) IPX_HIP(hipMemcpyAsync(nb, ix->Xh, old_bytes, hipMemcpyDeviceToDevice, st));
-    IPX_HIP(hipMemsetAsync((char*)nb + old_bytes, 0, new_bytes - old_bytes, st));
-    if (ix->Xh) {
-        IPX_HIP(hipStreamSynchronize(st));
-        (void)hipFree(ix->Xh);
+    hipError_t ce = old_bytes ? hipMemcpyAsync(nb, ix->Xh, old_bytes, hipMemcpyDeviceToDevice, st) : hipSuccess;
+    if (ce == hipSuccess) ce = hipMemsetAsync((char*)nb + old_bytes, 0, new_bytes - old_bytes, st);
+    if (ce == hipSuccess && ix->Xh) ce = hipStreamSynchronize(st);
+    if (ce != hipSuccess) {
+        (void)hipFree(nb);
+        return fail(IPX_ERR_HIP, std::string("grow bf16 corpus: ") + hipGetErrorString(ce));
     }
+    if (ix->Xh) (void)hipFree(ix->Xh);
     ix->Xh = nb;
     ix->cap_tiles_h = new_tiles;
     return 0;
@@ -181,11 +185,11 @@ int add_device_rows(ipx_index* ix, const void* rows, int dtype, int64_t m, int64
         if (int rc = launch_pack(rows, dtype, m, m, ix->d, ix->Xp, row0, ipx::BD, ix->nks, nullptr, 0, 0, st)) return rc;
     if (ix->storage != 0) {
         if (int rc = launch_pack_bf16(rows, dtype, m, m, ix->d, ix->Xh, row0, ipx::HBD, ix->nks_h, 1, st)) return rc;
-        // the margin bound uses |x|_2 of the values the exact score is defined on: the fp32 rows
-        // (storage 1) or the stored bf16 rows (storage 2; rounding can only matter upwards by 2^-8)
+        // the margin rule's corpus-side numbers: max |x|_2 of the values the exact score is defined on
+        // (the fp32 rows in storage 1, the stored bf16 rows in storage 2) and max |x - bf16(x)|_2
         const int blocks = (int)std::min<int64_t>((m + 3) / 4, 4096);
         hipLaunchKernelGGL(ipx::row_sumsq_max_kernel, dim3(blocks), dim3(256), 0, st, rows, dtype, m, ix->d,
-                           (uint32_t*)ix->maxsq.p);
+                           (uint32_t*)ix->maxsq.p, ix->storage);
         IPX_HIP(hipGetLastError());
     }
     return 0;
@@ -422,20 +426,12 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
     return 0;
 }
 
-// Error coefficient of the margin rule (rescore_kernel): |approx - exact| <= coef * |q| * max|x|.
-//   rounding to bf16 (to nearest, unit roundoff u = 2^-9): of x, unless the rows are stored bf16
-//   and the exact score is defined on them; of q, u with one part, u^2 (+ slack: 2^-17) with the
-//   hi + lo split; cross terms included by multiplying out (1+ex)(1+eq) - 1;
-//   fp32 accumulation of the exact chain: (d+1) * 2^-24; of the MFMA chain (d products per part):
-//   4x that, in case the matrix core's internal adds are not round-to-nearest; 0.2 % slack for the
-//   fp32 norms.
-float margin_coef(int d_pad, bool rows_exact_bf16, int qparts) {
-    const double u = 1.0 / 512.0;
-    const double ex = rows_exact_bf16 ? 0.0 : u;
-    const double eq = qparts == 2 ? 1.0 / 131072.0 : u;
-    const double round_err = (1.0 + ex) * (1.0 + eq) - 1.0;
-    const double acc_err = (1.0 + 4.0 * qparts) * (d_pad + 1) / 16777216.0;
-    return (float)((round_err + acc_err) * 1.002);
+// Accumulation-error coefficient of the margin rule (rescore_kernel; the rounding terms are
+// measured, not bounded: see row_sumsq_max_kernel): the exact fp32 chain contributes (d+1) 2^-24,
+// the MFMA chain d 2^-24 per query part, taken 4x in case the matrix core's internal adds are not
+// round-to-nearest; 0.2 % slack for the fp32 norms.
+float margin_acc_coef(int d_pad, int qparts) {
+    return (float)((1.0 + 4.0 * qparts) * (d_pad + 1) / 16777216.0 * 1.002);
 }
 
 // One bf16 pass over nq row-major fp32 queries (device): pack -> bf16 scan keeping kc candidates
@@ -562,7 +558,8 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     rp.outI = dI;
     rp.flags = (int*)ix->flags.p;
     rp.id_base = ix->id_base;
-    rp.coef = margin_coef(ix->nks_h * ipx::HBK, ix->storage == 2, qparts);
+    rp.acc_coef = margin_acc_coef(ix->nks_h * ipx::HBK, qparts);
+    rp.qparts = qparts;
     rp.d = d;
     rp.k = k;
     rp.kc = kc;

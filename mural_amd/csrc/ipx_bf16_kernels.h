@@ -144,28 +144,41 @@ pack_rows_bf16_kernel(const void* __restrict__ src, int dtype, int64_t n, int64_
     }
 }
 
-// max over rows of sum_i x_i^2 (fp32), as float bits in *maxsq (non-negative floats order like
-// unsigned ints; NaN / inf end up on top and make every margin check fail, which is intended).
+// The two corpus-side numbers of the margin rule (rescore_kernel), as float bits (non-negative floats
+// order like unsigned ints; NaN / inf end up on top and make every margin check fail, which is
+// intended):
+//   maxsq[0] = max over rows of |x|^2 of the values the exact score is defined on: the fp32 rows
+//              (mode 1) or the stored, rounded rows bf16(x) (mode 2);
+//   maxsq[1] = max over rows of |x - bf16(x)|^2, the ACTUAL rounding error of the scanned copy
+//              (mode 1; 0 in mode 2, where the scanned rows are the exact ones).
 // One wave per row, grid-stride.
 __global__ void __launch_bounds__(256)
-row_sumsq_max_kernel(const void* __restrict__ src, int dtype, int64_t n, int d, uint32_t* __restrict__ maxsq) {
+row_sumsq_max_kernel(const void* __restrict__ src, int dtype, int64_t n, int d, uint32_t* __restrict__ maxsq, int mode) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    float best = 0.f;
+    float best = 0.f, dbest = 0.f;
     bool bad = false;
     for (int64_t r = wave; r < n; r += nwaves) {
-        float s = 0.f;
+        float s = 0.f, ds = 0.f;
         for (int e = lane; e < d; e += 64) {
             const float x = load_as_f32(src, dtype, r * (int64_t)d + e);
-            s = fmaf(x, x, s);
+            const float xr = __uint_as_float((uint32_t)f32_to_bf16_rne(x) << 16);
+            const float v = mode == 2 ? xr : x;
+            const float dx = x - xr;
+            s = fmaf(v, v, s);
+            ds = fmaf(dx, dx, ds);
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (!(s <= FLT_MAX)) bad = true;      // NaN or inf
+        for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); ds += __shfl_xor(ds, off); }
+        if (!(s <= FLT_MAX) || !(ds <= FLT_MAX)) bad = true;      // NaN or inf
         best = fmaxf(best, s);
+        dbest = fmaxf(dbest, ds);
     }
-    if (lane == 0) atomicMax(maxsq, bad ? 0x7fc00000u : __float_as_uint(best));
+    if (lane == 0) {
+        atomicMax(maxsq, bad ? 0x7fc00000u : __float_as_uint(best));
+        if (mode != 2) atomicMax(maxsq + 1, bad ? 0x7fc00000u : __float_as_uint(dbest));
+    }
 }
 
 // ---- bf16 scan ---------------------------------------------------------------------------------
@@ -647,25 +660,36 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
 }
 
 // ---- rescore: candidates (approximate scores) -> exact fp32 scores -> top-k ---------------------
-// Margin rule. Let e be a bound on |approx - exact| for this query over every row (host supplies
-// coef; e = coef * |q|_2 * max_x |x|_2, a Cauchy-Schwarz bound on the bf16 rounding of both
-// operands plus the fp32 accumulation of both chains). Let a_k be the k-th best approximate
-// score. The k rows with the best approximate scores all have exact scores >= a_k - e, so the
-// exact k-th best score is >= a_k - e, so every row of the exact top-k has an approximate score
-// >= a_k - 2e. If the candidate list (the K' best approximate scores) reaches below a_k - 2e —
-// or holds every admissible row of the index — it contains the exact top-k: flag = 0.
-// Otherwise flag = 1 and the host repeats the query on the fp32 scan.
+// Margin rule. Notation: q the fp32 query, q^ = the bf16 part(s) the scan multiplied (hi, or
+// hi + lo), dq = q - q^; x a row the exact score is defined on, x^ its scanned bf16 copy,
+// dx = x - x^ (0 when the index stores bf16 rows only). approx = MFMA chain of q^.x^, exact =
+// the fp32 scan's chain of q.x. Then
+//   |approx - exact| <= |q^.x^ - q.x| + (accumulation of both chains)
+//                     = |q^.dx + dq.x| + acc  <=  (|q| + |dq|) Dx + |dq| Mx + acc =: e
+// with Mx = max_x |x|_2 and Dx = max_x |dx|_2 measured when the rows were added
+// (row_sumsq_max_kernel: the actual rounding errors, not the worst case 2^-8 |x| — typically
+// 0.4 of it), |q| and |dq| computed here from the query itself, and
+// acc = acc_coef (|q| + |dq|)(Mx + Dx): (d+1) 2^-24 for the exact chain plus 4 d 2^-24 per query
+// part for the MFMA chain (4x in case the matrix core's adds are not round-to-nearest; the
+// products of two bf16 numbers are exact in fp32). 0.2 % slack covers the fp32 norms.
+// Let a_k be the k-th best approximate score. The k rows with the best approximate scores all have
+// exact scores >= a_k - e, so the exact k-th best score is >= a_k - e, so every row of the exact
+// top-k has an approximate score >= a_k - 2e. If the candidate list (the K' best approximate
+// scores) reaches below a_k - 2e — or holds every admissible row of the index — it contains the
+// exact top-k: flag = 0. Otherwise flag = 1 and the host repeats the query with a longer list or
+// on the fp32 scan.
 struct RescoreParams {
     const float* candD;      // [nq][kc] approximate scores, descending
     const int64_t* candI;    // [nq][kc] id_base + row, -1 = empty (at the end)
     const float* q;          // [nq][d] fp32 queries, row-major
     const void* X;           // packed corpus: fp32 (tiles of 128) or bf16 (tiles of 256)
-    const uint32_t* maxsq;   // float bits of max_x sum x_i^2
+    const uint32_t* maxsq;   // float bits of max_x |x|^2 and max_x |x - bf16(x)|^2
     float* outD;             // [nq][k]
     int64_t* outI;           // [nq][k]
     int* flags;              // [nq]
     int64_t id_base;
-    float coef;
+    float acc_coef;          // accumulation-error coefficient (host: margin_acc_coef)
+    int qparts;              // bf16 parts of the query the scan used (1: hi, 2: hi + lo)
     int d, nks, x_is_bf16, k, kc, P;
 };
 
@@ -681,23 +705,29 @@ rescore_kernel(const RescoreParams p) {
     const int dpad = p.nks * (p.x_is_bf16 ? 32 : 16);
     float* qs = (float*)smem;                                  // [dpad]
     uint64_t* keys = (uint64_t*)(smem + (size_t)((dpad * 4 + 15) & ~15));   // [P]
-    __shared__ float red[4];
+    __shared__ float red[8];
     __shared__ int s_m;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t qi = blockIdx.x;
     const float* q = p.q + qi * (int64_t)p.d;
-    float ss = 0.f;
+    float ss = 0.f, dd = 0.f;
     for (int e = tid; e < dpad; e += 256) {
         const float v = e < p.d ? q[e] : 0.f;
         qs[e] = v;
         ss = fmaf(v, v, ss);
+        // what the scan did not see of this element (pack_rows_bf16_kernel's rounding, replayed)
+        float rest = v - __uint_as_float((uint32_t)f32_to_bf16_rne(v) << 16);
+        if (p.qparts == 2) rest -= __uint_as_float((uint32_t)f32_to_bf16_rne(rest) << 16);
+        dd = fmaf(rest, rest, dd);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-    if (lane == 0) red[wave] = ss;
+    for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off); dd += __shfl_xor(dd, off); }
+    if (lane == 0) { red[wave] = ss; red[4 + wave] = dd; }
     __syncthreads();
-    const float qsq = red[0] + red[1] + red[2] + red[3];
-    const float eps = p.coef * sqrtf(qsq) * sqrtf(__uint_as_float(*p.maxsq));
+    const float qn = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float dqn = sqrtf(red[4] + red[5] + red[6] + red[7]);
+    const float Mx = sqrtf(__uint_as_float(p.maxsq[0])), Dx = sqrtf(__uint_as_float(p.maxsq[1]));
+    const float eps = 1.002f * ((qn + dqn) * Dx + dqn * Mx) + p.acc_coef * (qn + dqn) * (Mx + Dx);
 
     const float* cD = p.candD + qi * (int64_t)p.kc;
     const int64_t* cI = p.candI + qi * (int64_t)p.kc;

@@ -210,3 +210,50 @@ def test_config2_scale_bf16scan_equals_fp32_scan(R):
     D0, I0 = ix.search_device(Q, k)
     ix.check()
     assert torch.equal(I0, I1) and torch.equal(D0.view(torch.int32), D1.view(torch.int32))
+
+
+def test_margin_rule_against_coherent_rounding_errors(R):
+    """Rounding errors that all pull the same way — the worst case the margin rule has to cover, with bf16's
+    unit roundoff 2^-8 per operand. The query rounds up on dims 0..31 and down on dims 32..63.
+      U rows (100): on dims 0..31, rounding up:   exact 32.25, approximate 32.50 (+0.25)
+      D rows (10):  on dims 32..63, rounding down: exact 32.30..32.34, approximate 32.05..32.09 (-0.25)
+      fillers (3000): exactly representable, exact 32.227, approximate 32.10
+    The exact top-10 are the D rows, but the approximate order is U > fillers > D: a candidate list of 256
+    ends among the fillers, 0.40 below the 10th best approximate score. A rule that assumed less than the
+    true error bound (2e >= 0.50 here) would trust that list and return U rows."""
+    d, k = 64, 10
+    up = np.float32(1 + 2.0 ** -8 + 2.0 ** -20)        # -> 1 + 2^-7 in bf16
+    down = np.float32(1 + 2.0 ** -8 - 2.0 ** -20)      # -> 1.0
+    q = np.concatenate([np.full(32, up), np.full(32, down)]).astype(np.float32)
+    U = np.zeros((100, d), np.float32)
+    U[:, :32] = up
+    U[:, 0] += np.arange(100, dtype=np.float32) * np.float32(2.0 ** -18)       # distinct scores, still rounding up
+    Dn = np.zeros((10, d), np.float32)
+    Dn[:, 32:63] = np.float32(1.0117)                   # just below the midpoint 1.01171875 -> 1.0078125
+    Dn[:, 63] = np.float32(0.8125) + np.arange(10, dtype=np.float32) * np.float32(2.0 ** -8)   # exact in bf16
+    F = np.zeros((3000, d), np.float32)
+    F[:, 32:] = 1.0
+    F[:, 63] = np.float32(1.1015625)
+    assert np.array_equal(bf16_round(F), F) and np.array_equal(bf16_round(Dn[:, 63]), Dn[:, 63])
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(3110)
+    X = np.concatenate([U, Dn, F])[perm]
+    Q = np.stack([q, q])
+    exact = X.astype(np.float64) @ q.astype(np.float64)
+    approx = bf16_round(X).astype(np.float64) @ bf16_round(q).astype(np.float64)
+    is_d = np.isin(perm, np.arange(100, 110))
+    assert set(np.argsort(-exact)[:k]) == set(np.flatnonzero(is_d))            # the construction holds:
+    a_k = np.sort(approx)[::-1][k - 1]
+    assert 0.36 < a_k - approx[is_d].max() < 0.50 and np.abs(approx - exact).max() > 0.25
+    assert (approx > approx[is_d].max()).sum() > 256                           # the 256-list ends above the D rows
+    ix = index(R, X, "bf16scan")
+    ix.set_param("query_parts", 1)
+    ix.set_param("bf16_candidates", 256)
+    D, I = ix.search(Q, k)
+    assert ix.last_bf16_stats()["fallback_queries"] == 2                       # caught, repeated
+    assert_bits(D, I, Q, X, k)
+    assert set(I[0].tolist()) == set(np.flatnonzero(is_d).tolist())
+    ix.set_param("query_parts", 0)
+    ix.set_param("bf16_candidates", 0)
+    D, I = ix.search(Q, k)
+    assert_bits(D, I, Q, X, k)
