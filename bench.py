@@ -156,7 +156,7 @@ def main():
 
     # ---- extras (not the headline): the bf16 scan on the same index, and small batches ----
     extra = {}
-    if args.storage == "bf16scan" and args.headline == "f32" and not args.no_extras:
+    if args.storage == "bf16scan" and args.headline == "f32" and not args.no_extras and world == 1:
         ix.set_param("f32_scan", 0)
         el2, sc2, D2, I2 = timed(Q, args.steps, 1)
         bf2, tm2, geo2 = ix.last_bf16_stats(), ix.last_timing(), ix.last_geometry()
