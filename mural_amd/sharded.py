@@ -4,13 +4,14 @@ This is the on-node replacement for the reference's sharded workflow
 (/root/reference/docs/retrieval.md:31-53: one `python -m tevatron.faiss_retriever` run per
 corpus shard, intermediate pickles, then reducer.py's ResultHeap merge): every rank holds a
 contiguous row block of the corpus in HBM, all ranks search the same queries, the per-rank
-(score, global id) candidates are exchanged with ONE all-gather (torch.distributed, backend
-"nccl" = RCCL over xGMI) and merged on the GPU by the same kernel that serves reducer.py
+(score, global id) candidates are exchanged with one all-gather per array (scores, ids;
+torch.distributed, backend "nccl" = RCCL over xGMI) and merged on the GPU by the same kernel that serves reducer.py
 (ipx_merge_topk). The result is identical to a single-index search because the top-k of a
 union is the top-k of the per-part top-k's, and ties break on the global id.
 
-The exchange is a direct all-gather of nq*k*(4+8) bytes per rank (6980 x 100: 8.4 MB), one
-collective per search; there is no other data-path communication.
+The exchange is a direct all-gather of nq*k*(4+8) bytes per rank (6980 x 100: 8.4 MB), two
+collectives per search (each gathers straight into the [world, nq, k] layout the merge kernel
+reads); there is no other data-path communication.
 """
 import ctypes as C
 
