@@ -214,8 +214,95 @@ def _load_index(pattern):
     return retriever, look_up
 
 
+def _assign_files(rows_per_file, world):
+    """Contiguous groups of shard files, balanced by rows: owner[i] = rank that loads file i.
+    Contiguous, so every rank's rows are one block [row_lo, row_hi) of the concatenated corpus."""
+    total = sum(rows_per_file)
+    owner, start = [], 0
+    for n in rows_per_file:
+        owner.append(min(world - 1, int((start + n / 2.0) * world / total)) if total else 0)
+        start += n
+    return owner
+
+
+def _main_sharded(args, engine_factory=None):
+    """`python -m torch.distributed.run --nproc-per-node G -m tevatron.faiss_retriever ...`: one process
+    per GPU, the shard files dealt to the ranks in contiguous groups, every rank searches all queries on its
+    rows, candidates all-gathered (RCCL) and merged on the GPU (mural_amd.sharded), rank 0 writes the
+    ranking. The output is the single-process output: global row ids are positions in the concatenation of
+    the shards in glob order, exactly what the reference's add loop produces (__main__.py:74-80), and the
+    merge breaks ties on them. This replaces the reference's per-shard runs + reducer (docs/retrieval.md:31-53).
+    `engine_factory(d)` injects the per-rank engine (CPU tests); the default is the HIP engine."""
+    import torch
+    import torch.distributed as dist
+    from ..sharded import ShardedFlatIP
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    index_files = glob.glob(args.passage_reps)
+    logger.info(f'Pattern match found {len(index_files)} files; loading them into index.')
+    index_files[0]                               # IndexError on every rank when nothing matches (__main__.py:71)
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if engine_factory is None:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 0 reads every shard's ids; the rows themselves are mapped, not read (pickle_load)
+        meta, look_up = [None], []
+        if rank == 0:
+            rows, dim = [], None
+            for f in index_files:
+                reps, lookup = pickle_load(f)
+                rows.append(int(reps.shape[0]))
+                dim = int(reps.shape[1]) if dim is None else dim
+                look_up += lookup
+            meta = [(rows, dim)]
+        dist.broadcast_object_list(meta, src=0)
+        rows, dim = meta[0]
+        owner = _assign_files(rows, world)
+        starts = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+        mine = [i for i, r in enumerate(owner) if r == rank]
+        row_lo = int(starts[mine[0]]) if mine else int(starts[-1])
+        index = ShardedFlatIP(dim, row_lo=row_lo, device=None if engine_factory else local,
+                              engine=engine_factory(dim) if engine_factory else None)
+        for i in mine:
+            p_reps, _ = pickle_load(index_files[i])
+            index.add_local(p_reps if p_reps.dtype == np.float16 else p_reps.astype('float32', copy=False))
+
+        q_reps, q_lookup = pickle_load(args.query_reps)
+        q_reps = q_reps.astype('float32')
+        logger.info('Index Search Start')
+        # chunking never changes a result here (a score does not depend on its batch): large chunks
+        chunk = q_reps.shape[0] if args.batch_size <= 0 else max(args.batch_size, 8192)
+        all_scores, all_indices = [], []
+        for lo in range(0, q_reps.shape[0], max(chunk, 1)):
+            D, I = index.search(q_reps[lo:lo + chunk], args.depth)
+            if rank == 0:
+                all_scores.append(D.cpu().numpy())
+                all_indices.append(I.cpu().numpy())
+        logger.info('Index Search Finished')
+        if rank == 0:
+            k = args.depth
+            all_scores = np.concatenate(all_scores) if all_scores else np.empty((0, k), np.float32)
+            all_indices = np.concatenate(all_indices) if all_indices else np.empty((0, k), np.int64)
+            psg_indices = _lookup_strings(look_up, all_indices)
+            if args.save_text:
+                write_ranking(psg_indices, all_scores, q_lookup, args.save_ranking_to)
+            else:
+                pickle_save((all_scores, psg_indices), args.save_ranking_to)
+        dist.barrier()
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
 def main(argv=None):
     args = _parse_args(argv)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return _main_sharded(args)
     retriever, look_up = _load_index(args.passage_reps)
 
     q_reps, q_lookup = pickle_load(args.query_reps)

@@ -38,9 +38,12 @@ class _HipEngine:
         self.index.set_id_base(base)
 
     def add(self, x):
-        self.index.add(x)
+        self.index.add(x)                # host (numpy) rows or a torch CUDA tensor
 
     def search(self, q, k):
+        import torch
+        if not torch.is_tensor(q):       # host queries: one copy up, results stay on the device for the exchange
+            q = torch.from_numpy(q).to(torch.device("cuda", self.device))
         return self.index.search_device(q, k)
 
     def merge(self, D, I, k_out):

@@ -399,3 +399,22 @@ def test_config2_scale_properties(R):
         del e
     mD, mI = _HipEngine(d, 0).merge(torch.stack(parts_D), torch.stack(parts_I), 100)
     assert torch.equal(mD, D) and torch.equal(mI, I)
+
+
+def test_cli_torchrun_mode_one_rank_equals_plain_cli(R, tmp_path, monkeypatch):
+    # the multi-process CLI path (_main_sharded) with a 1-rank RCCL group on this GPU: HIP engine wiring,
+    # host rows / host queries in, byte-identical ranking out
+    import socket
+    from mural_amd.faiss_retriever import __main__ as drv
+    argv = ["--query_reps", os.path.join(GOLDEN_DIR, "E_query_emb.pkl"),
+            "--passage_reps", os.path.join(GOLDEN_DIR, "E_corpus_emb*.pkl"),
+            "--depth", "10", "--batch_size", "4", "--save_text", "--quiet", "--save_ranking_to"]
+    drv.main(argv + [str(tmp_path / "plain.tsv")])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    for key, val in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"),
+                     ("MASTER_PORT", str(port))):
+        monkeypatch.setenv(key, val)
+    drv._main_sharded(drv._parse_args(argv + [str(tmp_path / "sharded.tsv")]))
+    assert (tmp_path / "sharded.tsv").read_bytes() == (tmp_path / "plain.tsv").read_bytes()

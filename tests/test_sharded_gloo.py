@@ -84,3 +84,69 @@ def test_shard_bounds_cover_rows_exactly():
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- the CLI under torch.distributed.run: shard files dealt to the ranks, rank 0 writes ----------
+class NumpyOracleEngine(OracleEngine):
+    def add(self, x):
+        x = np.asarray(x, dtype=np.float32)
+        self.X = x if self.X is None else np.concatenate([self.X, x])
+
+    def search(self, q, k):
+        q = q.numpy() if torch.is_tensor(q) else np.asarray(q, dtype=np.float32)
+        if self.X is None:                                   # a rank that owns no shard file
+            return (torch.full((q.shape[0], k), -np.finfo(np.float32).max), torch.full((q.shape[0], k), -1, dtype=torch.int64))
+        D, I = self.O.topk_total_order(self.O.scores_mfma_order(q, self.X), k, id_base=self.base)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+
+def _cli_worker(rank, world, port, tmp, depth):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    from mural_amd.faiss_retriever import __main__ as drv
+    args = drv._parse_args(["--query_reps", os.path.join(tmp, "q.pkl"), "--passage_reps", os.path.join(tmp, "corpus_emb*.pkl"),
+                            "--depth", str(depth), "--batch_size", "4", "--save_ranking_to", os.path.join(tmp, "rank.tsv"),
+                            "--save_text", "--quiet"])
+    drv._main_sharded(args, engine_factory=NumpyOracleEngine)
+
+
+@pytest.mark.parametrize("world,nfiles", [(2, 3), (2, 1), (3, 2)])
+def test_cli_under_torchrun_equals_single_process_output(tmp_path, world, nfiles):
+    import glob
+    import pickle
+    from oracle import oracle as O
+    from mural_amd.faiss_retriever import __main__ as drv
+    d, nq, depth = 24, 9, 7
+    rng = np.random.default_rng(99)
+    sizes = [57, 131, 20][:nfiles]
+    for i, n in enumerate(sizes):
+        reps = rng.standard_normal((n, d), dtype=np.float32)
+        if i == 1:
+            reps = reps.astype(np.float16)
+        with open(tmp_path / f"corpus_emb{i}.pkl", "wb") as f:
+            pickle.dump((reps, [f"D{i}_{j}" for j in range(n)]), f)
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    with open(tmp_path / "q.pkl", "wb") as f:
+        pickle.dump((Q, [str(100 + j) for j in range(nq)]), f)
+    mp.spawn(_cli_worker, args=(world, _free_port(), str(tmp_path), depth), nprocs=world, join=True)
+    # expected: the shards concatenated in glob order (what the single-process add loop builds)
+    X, look = [], []
+    for f in glob.glob(str(tmp_path / "corpus_emb*.pkl")):
+        reps, lk = drv.pickle_load(f)
+        X.append(np.asarray(reps, dtype=np.float32))
+        look += lk
+    X = np.concatenate(X)
+    rD, rI = O.topk_total_order(O.scores_mfma_order(Q, X), depth)
+    drv.write_ranking(drv._lookup_strings(look, rI), rD, [str(100 + j) for j in range(nq)], str(tmp_path / "want.tsv"))
+    assert (tmp_path / "rank.tsv").read_bytes() == (tmp_path / "want.tsv").read_bytes()
+    assert len((tmp_path / "rank.tsv").read_bytes().splitlines()) == nq * depth
+
+
+def test_assign_files_contiguous_and_balanced():
+    from mural_amd.faiss_retriever.__main__ import _assign_files
+    assert _assign_files([10, 10, 10, 10], 2) == [0, 0, 1, 1]
+    assert _assign_files([100], 4) == [2] or _assign_files([100], 4)[0] in range(4)
+    for rows, w in (([5, 1, 1, 1, 5, 7, 2], 3), ([1] * 20, 8), ([3, 3], 8), ([0, 0], 2)):
+        o = _assign_files(rows, w)
+        assert o == sorted(o) and all(0 <= r < w for r in o)
