@@ -135,6 +135,9 @@ int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in
  *                  the query, twice the MFMA work, a far smaller margin); 0 = automatic.
  *   "f32_scan"   : 1 = storage 1 searches with the fp32 scan (A/B measurements on one index).
  *   "max_splits" : upper bound on the corpus splits per query block (0 = automatic).
+ *   "small_f32_limit" : fp32 scans of up to this many queries use the 32/64-query tile that
+ *                  streams the corpus at the HBM rate (default 192; results do not depend on it).
+ *   "no_small_batch" : 1 = always use the 256-query tiles (A/B measurements, tests).
  *   "trace"      : 1 = every scan workgroup records {start, end (100 MHz ticks), HW_ID,
  *                  compactions}; read back with ipx_read_trace (profiling aid). */
 int ipx_set_param(ipx_index* idx, const char* name, int64_t value);
