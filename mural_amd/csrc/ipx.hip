@@ -455,7 +455,8 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     const int resident = prop.multiProcessorCount;          // one 512-thread workgroup per CU
     int S = std::max(1, resident / nqb);
     if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
-    const int R = std::max(4, std::min(64, ntiles / (S * 64)));
+    int R = 4;                                               // tiles per run: a power of two in [4, 64]
+    while (R < 64 && 2 * R <= ntiles / (S * 64)) R *= 2;
     const int nruns = (ntiles + R - 1) / R;
     S = std::min(S, nruns);
     const int G = nqb * S;

@@ -356,30 +356,20 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
     const uint32_t b_off = HSTAGE_A + (wq * (32 * QW) + l31) * 64;
     const uint32_t pc0 = ((0 + h) ^ sw) * 16, pc1 = ((2 + h) ^ sw) * 16;
 
-    const int R = p.run_tiles;
-    int adv_end = (split + 1) * R < p.ntiles ? (split + 1) * R : p.ntiles;
-    int nxt = -1, enter_t = -1;
-    // Runs are dealt round-robin: split s takes runs s, s + S, s + 2S, ... (one workgroup per CU
-    // here, so there are no fast / slow pairs to balance dynamically as in the fp32 kernel).
-    int my_run = split;
-    auto claim_next_run = [&]() {
-        my_run += p.S;
-        nxt = (int64_t)my_run * R < p.ntiles ? my_run * R : -1;
-        enter_t = -1;
-    };
+    // Runs of R tiles (R a power of two) are dealt round-robin: split s takes runs s, s + S,
+    // s + 2S, ... (one workgroup per CU here, so there are no fast / slow pairs to balance
+    // dynamically as in the fp32 kernel). A cursor finds its successor by itself — the stage ring
+    // may look further ahead than one run is long (one K-stage per tile when d <= 32).
+    const int R = p.run_tiles, logR = __builtin_ctz((unsigned)R);
     auto advance = [&](StageCursor c) {
         if (!c.ok) return c;
         if (++c.ks < p.nks) return c;
         c.ks = 0;
-        if (c.t + 1 < adv_end) { ++c.t; return c; }
-        if (nxt >= 0) {
-            c.t = nxt;
-            enter_t = nxt;
-            adv_end = nxt + R < p.ntiles ? nxt + R : p.ntiles;
-            nxt = -1;
-            return c;
-        }
-        c.ks = p.nks - 1;
+        const int t1 = c.t + 1;
+        if ((t1 & (R - 1)) != 0 && t1 < p.ntiles) { c.t = t1; return c; }      // still inside the run
+        const int64_t next = ((int64_t)(c.t >> logR) + p.S) << logR;
+        if (next < p.ntiles) { c.t = (int)next; return c; }
+        c.ks = p.nks - 1;      // past the end: keep re-reading the last real stage into a buffer nobody reads
         c.ok = false;
         return c;
     };
@@ -387,7 +377,6 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
     // cur[0] = stage being computed (ring slot `slot`), cur[1..NBUF-1] = in flight, cur[NBUF] = next to issue
     StageCursor cur[NBUF + 1];
     cur[0] = StageCursor{split * R, 0, split * R < p.ntiles};
-    claim_next_run();
 #pragma unroll
     for (int i = 1; i <= NBUF; ++i) cur[i] = advance(cur[i - 1]);
 #pragma unroll
@@ -409,7 +398,6 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
     if (p.trace) tr_begin = __builtin_readcyclecounter();
     while (cur[0].ok) {
         const int t = cur[0].t;
-        if (t == enter_t) claim_next_run();
         f32x16 acc[2][QW];
 #pragma unroll
         for (int i = 0; i < 2; ++i)

@@ -257,3 +257,33 @@ def test_margin_rule_against_coherent_rounding_errors(R):
     ix.set_param("bf16_candidates", 0)
     D, I = ix.search(Q, k)
     assert_bits(D, I, Q, X, k)
+
+
+@pytest.mark.parametrize("storage", ["bf16scan", "bf16"])
+@pytest.mark.parametrize("nq", [32, 300])
+def test_short_rows_many_runs_per_workgroup(R, storage, nq):
+    """d <= 32: one K-stage per corpus tile, so the stage ring looks ahead further than a 4-tile run is long.
+    (Regression: the look-ahead cursor once needed a run that was only handed out when the computing cursor
+    got there, and the workgroup stopped after its first runs — found by scripts/fuzz_parity.py.)"""
+    X, Q = gaussian(41, (58317, 7)), gaussian(42, (nq, 7))
+    Xe = bf16_round(X) if storage == "bf16" else X
+    ix = index(R, X, storage, adds=2)
+    for max_splits in (1, 5, 0):
+        ix.set_param("max_splits", max_splits)
+        for parts in (1, 2):
+            ix.set_param("query_parts", parts)
+            D, I = ix.search(Q, 100)
+            assert ix.last_bf16_stats()["candidates"] > 0
+            assert_bits(D, I, Q, Xe, 100)
+
+
+def test_randomised_differential_cases(R):
+    """A bounded run of scripts/fuzz_parity.py (random shapes, depths, split caps, storage modes, tie-heavy data,
+    every scan variant against the oracle, bit for bit)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_parity.py"), "120", "7"],
+                         capture_output=True, text=True, timeout=250)
+    assert out.returncode == 0 and "all 120 cases ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
