@@ -724,7 +724,9 @@ merge_topk_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, in
             if (i < k_in) {
                 // ResultHeap only admits scores strictly above its neutral value
                 // (-FLT_MAX after the reducer's negation); NaN never compares true.
-                const float sc = d[i];
+                // (+ 0.0f: a -0.0 score ties with +0.0, as it does under faiss's float compares;
+                // the scans never produce one, a caller's shard results may hold one)
+                const float sc = d[i] + 0.0f;
                 if (sc > -FLT_MAX) { o = f32_ordered(sc); id = ids[i]; }
             }
             los[i] = o; lid[i] = id;

@@ -5,6 +5,7 @@ rounded rows). Usage: fuzz_parity.py <cases> <seed>."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch
 from oracle import oracle as O
 from mural_amd.faiss_retriever.retriever import FlatIPIndex
 
@@ -39,8 +40,25 @@ for c in range(cases):
     adds = int(rng.choice([1, 1, 2, 5]))
     ix = FlatIPIndex(d, storage=storage)
     step = -(-n // adds)
+    if rng.random() < 0.3:
+        ix.reserve(int(rng.integers(0, 2 * n + 2)))
+    X = X.copy()
     for lo in range(0, n, step):
-        ix.add(X[lo:lo + step])
+        how = rng.choice(["f32", "f16", "torch_f32", "torch_bf16"])
+        part = X[lo:lo + step]
+        if how == "f16":                                  # float16 shards are widened on the device
+            h = np.clip(part, -60000, 60000).astype(np.float16)
+            X[lo:lo + step] = h.astype(np.float32)
+            ix.add(h)
+        elif how == "torch_f32":
+            ix.add(torch.from_numpy(part).cuda())
+        elif how == "torch_bf16":
+            t = torch.from_numpy(part).cuda().to(torch.bfloat16)
+            X[lo:lo + step] = t.float().cpu().numpy()
+            ix.add(t)
+        else:
+            ix.add(part)
+    assert ix.ntotal == n
     ix.set_param("max_splits", ms)
     Xe = bf16_round(X) if storage == "bf16" else X
     rD, rI = O.topk_total_order(O.scores_mfma_order(Q, Xe), k)

@@ -418,3 +418,22 @@ def test_cli_torchrun_mode_one_rank_equals_plain_cli(R, tmp_path, monkeypatch):
         monkeypatch.setenv(key, val)
     drv._main_sharded(drv._parse_args(argv + [str(tmp_path / "sharded.tsv")]))
     assert (tmp_path / "sharded.tsv").read_bytes() == (tmp_path / "plain.tsv").read_bytes()
+
+
+def test_merge_negative_zero_ties_with_zero(R):
+    # -0.0 == +0.0 under float compares (faiss's order): the tie breaks on the id, not on the sign bit
+    Ds = np.array([[[0.0, -0.0, 1.0, -0.0]], [[-0.0, 0.0, -1.0, 0.0]]], np.float32)
+    Is = np.array([[[40, 10, 5, 30]], [[20, 50, 6, 0]]], np.int64)
+    oD, oI = gpu_merge(Ds, Is, 8)
+    assert oI.tolist() == [[5, 0, 10, 20, 30, 40, 50, 6]]
+    assert np.array_equal(oD, np.array([[1, 0, 0, 0, 0, 0, 0, -1]], np.float32))
+
+
+def test_randomised_merge_and_entry_point_cases(R):
+    """A bounded run of scripts/fuzz_merge.py (merge kernel: random list counts, depths, ties, holes, NaN;
+    id base, aspect-fused and plain queries on both storage modes), bit for bit against the oracle."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_merge.py"), "100", "5"],
+                         capture_output=True, text=True, timeout=250)
+    assert out.returncode == 0 and "all 100 cases ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
