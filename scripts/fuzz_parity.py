@@ -15,12 +15,17 @@ def bf16_round(x):
     return u.astype(np.uint32).view(np.float32)
 
 cases, seed = int(sys.argv[1]), int(sys.argv[2])
+HEAVY = os.environ.get('HEAVY') == '1'
 rng = np.random.default_rng(seed)
 t0 = time.time()
 for c in range(cases):
     n = int(rng.choice([1, 2, 127, 128, 129, 255, 256, 257, 511, 513, int(rng.integers(1, 3000)), int(rng.integers(3000, 60000))]))
     d = int(rng.choice([1, 7, 8, 16, 17, 31, 32, 33, 48, 64, 100, 128, int(rng.integers(1, 300))]))
     nq = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 192, 193, 256, 257, int(rng.integers(1, 400))]))
+    if HEAVY:          # long scans: many tiles per workgroup, queue pressure, compaction episodes
+        n = int(rng.integers(150_000, 900_000))
+        d = int(rng.choice([8, 16, 32, 33, 64]))
+        nq = int(rng.choice([1, 20, 64, 70, 300]))
     k = int(rng.choice([1, 2, 10, 100, 255, 256, 257, 1000, 1024, 1638, 2048, int(rng.integers(1, 2049))]))
     kind = rng.choice(["gauss", "ties", "quant", "ramp"])
     if kind == "gauss":
