@@ -16,12 +16,15 @@ def bf16_round(x):
 
 cases, seed = int(sys.argv[1]), int(sys.argv[2])
 HEAVY = os.environ.get('HEAVY') == '1'
+BIGD = os.environ.get('BIGD') == '1'
 rng = np.random.default_rng(seed)
 t0 = time.time()
 for c in range(cases):
     n = int(rng.choice([1, 2, 127, 128, 129, 255, 256, 257, 511, 513, int(rng.integers(1, 3000)), int(rng.integers(3000, 60000))]))
     d = int(rng.choice([1, 7, 8, 16, 17, 31, 32, 33, 48, 64, 100, 128, int(rng.integers(1, 300))]))
     nq = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 192, 193, 256, 257, int(rng.integers(1, 400))]))
+    if BIGD:           # long rows: many K-stages per tile
+        n = int(rng.integers(1, 3000)); d = int(rng.choice([768, 1000, 1024, 4096, 8192])); nq = int(rng.choice([1, 33, 70, 260]))
     if HEAVY:          # long scans: many tiles per workgroup, queue pressure, compaction episodes
         n = int(rng.integers(150_000, 900_000))
         d = int(rng.choice([8, 16, 32, 33, 64]))
