@@ -265,7 +265,11 @@ template <int QW>
 __device__ __forceinline__ void read_b(f32x4 (&b)[QW], uint32_t bb) {
     IPX_DS_READ_B128(b[0], bb, 0);
     if constexpr (QW == 4) {
+#ifdef IPX_ABL_HALF_B_READS   // diagnostic build: a third fewer operand reads from LDS (results are meaningless)
+        IPX_DS_READ_B128(b[1], bb, 2048);
+#else
         IPX_DS_READ_B128(b[1], bb, 2048); IPX_DS_READ_B128(b[2], bb, 4096); IPX_DS_READ_B128(b[3], bb, 6144);
+#endif
     }
 }
 // s_waitcnt lgkmcnt(N) that the compiler sees as (re)defining the operand registers waited for, so
@@ -302,7 +306,11 @@ __device__ __forceinline__ void mfma_set(f32x16 (&acc)[2][QW], const f32x4 (&a)[
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < QW; ++j)
+#ifdef IPX_ABL_HALF_B_READS
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[i]), as_bf16x8(b[j & 1]), acc[i][j], 0, 0, 0);
+#else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[i]), as_bf16x8(b[j]), acc[i][j], 0, 0, 0);
+#endif
     pin_acc<QW>(acc);
 }
 
@@ -410,7 +418,11 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             const int nslot = slot + 1 == NBUF ? 0 : slot + 1;
             const uint32_t buf = smem_base + slot * STAGE;
             const uint32_t nbuf = smem_base + nslot * STAGE;
+#ifdef IPX_ABL_HALF_B_READS
+            constexpr int NB = QW == 4 ? 2 : QW;
+#else
             constexpr int NB = QW;                 // LDS reads per B operand set
+#endif
             if constexpr (QP == 1) {
                 // first half: set 1 is read while set 0 (read one half-stage ago) is multiplied
                 read_a<QW>(A[1], buf + a_off + pc1);
@@ -440,7 +452,11 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             __builtin_amdgcn_sched_barrier(0);
             // the stage's last operands are in registers (so nobody reads its buffer any more), the
             // next stage has landed (NBUF - 2 younger stages may still be in flight)
+#ifdef IPX_ABL_HALF_B_READS
+#define IPX_MFMA1(i_, j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A[1][i_]), as_bf16x8(B[1][(j_) & 1]), acc[i_][j_], 0, 0, 0)
+#else
 #define IPX_MFMA1(i_, j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A[1][i_]), as_bf16x8(B[1][j_]), acc[i_][j_], 0, 0, 0)
+#endif
             // the addresses of the next copy pieces are worked out before the barrier, and the first
             // MFMAs of the last phase go out right behind it: the matrix core has work queued while
             // this wave issues the next stage's operand reads
