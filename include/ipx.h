@@ -138,6 +138,8 @@ int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in
  *   "small_f32_limit" : fp32 scans of up to this many queries use the 32/64-query tile that
  *                  streams the corpus at the HBM rate (default 192; results do not depend on it).
  *   "no_small_batch" : 1 = always use the 256-query tiles (A/B measurements, tests).
+ *   "bf16_waves" : large-batch bf16 scan with 8 or 16 waves per workgroup (0 = automatic: 16 with
+ *                  one query part, 8 with two; results do not depend on it).
  *   "trace"      : 1 = every scan workgroup records {start, end (100 MHz ticks), HW_ID,
  *                  compactions}; read back with ipx_read_trace (profiling aid). */
 int ipx_set_param(ipx_index* idx, const char* name, int64_t value);

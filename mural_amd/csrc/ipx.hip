@@ -6,6 +6,7 @@
 // IPX_ERR_HIP.
 #include "ipx_bf16_kernels.h"
 #include "ipx_f32_small_kernels.h"
+#include "ipx_bf16_w16_kernels.h"
 #include "../../include/ipx.h"
 
 #include <algorithm>
@@ -91,6 +92,7 @@ struct ipx_index {
     int force_kc = 0;        // 0 = automatic candidate count
     int query_parts = 0;     // 0 = automatic; 1 / 2 bf16 parts per query in the bf16 scan
     int small_f32_limit = 192;     // fp32 scans of up to this many queries take scan_f32_small_kernel
+    int bf16_waves = 0;            // large-batch bf16 scan: 8 (scan_bf16_kernel<4>) or 16 waves (scan_bf16_w16_kernel); 0 = automatic
     bool no_small_batch = false;   // diagnostic: always use the 256-query bf16 scan variant
     bool force_f32_scan = false;   // storage 1: use the fp32 scan although a bf16 copy exists
     size_t tile_bytes() const { return (size_t)nks * ipx::STAGE_A_BYTES; }
@@ -512,11 +514,15 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     p.ntiles = ntiles;
     const int lds = std::max(ring, nsortwaves * cap * 8) + ipx::LDS_STATE_BYTES;
     {
+        // one query part: the 16-wave variant is 9 % faster (8.8M x 768, 6980 queries: 93 vs 102 ms);
+        // hi + lo parts: no difference, the 8-wave kernel stays
+        const bool w16 = !small && (ix->bf16_waves == 16 || (ix->bf16_waves == 0 && qparts == 1));
         void (*kern)(const ipx::ScanParams, const int) =
             small ? (qparts == 2 ? ipx::scan_bf16_kernel<1, 2> : ipx::scan_bf16_kernel<1, 1>)
+            : w16 ? (qparts == 2 ? ipx::scan_bf16_w16_kernel<2> : ipx::scan_bf16_w16_kernel<1>)
                   : (qparts == 2 ? ipx::scan_bf16_kernel<4, 2> : ipx::scan_bf16_kernel<4, 1>);
         IPX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(kern, dim3(G), dim3(ipx::HTHREADS), lds, st, p, nsortwaves);
+        hipLaunchKernelGGL(kern, dim3(G), dim3(w16 ? 1024 : ipx::HTHREADS), lds, st, p, nsortwaves);
     }
     IPX_HIP(hipGetLastError());
     if (timing) IPX_HIP(hipEventRecord(ix->ev[2], st));
@@ -1034,6 +1040,11 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
             return fail(IPX_ERR_STATE, "set_param: storage can only be chosen while the index is empty and unreserved");
         if (value != 0 && ix->d > 8192) return fail(IPX_ERR_ARG, "set_param: bf16 storage needs d <= 8192");
         ix->storage = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "bf16_waves")) {
+        if (value != 0 && value != 8 && value != 16) return fail(IPX_ERR_ARG, "set_param: bf16_waves must be 0, 8 or 16");
+        ix->bf16_waves = (int)value;
         return 0;
     }
     if (!strcmp(name, "small_f32_limit")) {

@@ -1,0 +1,241 @@
+// bf16 scan, 16-wave variant of the 256 x 256 tile (large batches). Why it exists: measured on gfx950, a wave
+// gets about one 1-KiB LDS-DMA copy piece through per ~230 ns however deep its ring is, so the fill rate of a
+// CU grows with the number of waves that copy. scan_bf16_kernel<4> has 8 waves with 4-6 pieces each per
+// 32-48 KiB stage and spends more time on its copies than on its MFMAs. Here 16 waves (1024 threads, 4 per
+// SIMD, <= 128 registers each) take a 64 x 64 corner of the tile each (acc 2 x 2) and 2-3 pieces per stage;
+// with four waves per SIMD the LDS read latency is hidden by the other waves, so the loop is plain: read an
+// operand set, wait, multiply. Same packed layouts, same streaming top-k machinery, same results.
+// Included by ipx.hip after ipx_bf16_kernels.h and ipx_f32_small_kernels.h.
+#pragma once
+
+namespace ipx {
+
+template <int QP> struct WCfg {
+    static constexpr int THREADS = 1024;
+    static constexpr int PART_B = 256 * 64;                  // one part of the query stage: 16 KiB
+    static constexpr int STAGE = HSTAGE_A + PART_B * QP;     // 32 / 48 KiB
+    static constexpr int NBUF = QP == 1 ? 4 : 3;             // ring: 128 / 144 KiB
+    static constexpr int LOADS = 1 + QP;                     // copy pieces per wave per stage
+    static constexpr int RING = NBUF * STAGE;
+};
+
+template <int QP>
+struct WPieces {
+    const char* ga;
+    const char* gb;
+    char* la;
+    __device__ __forceinline__ WPieces(const ScanParams& p, char* buf, int64_t tile, int qb, int ks, int wave, int lane) {
+        ga = (const char*)p.Xp + ((size_t)tile * p.nks + ks) * HSTAGE_A + wave * 1024 + lane * 16;
+        gb = (const char*)p.Qp + ((size_t)qb * p.nks + ks) * (WCfg<QP>::PART_B * QP) + wave * 1024 + lane * 16;
+        la = buf + wave * 1024;
+    }
+    __device__ __forceinline__ void issue_all() const {
+        IPX_GLDS(ga, la);
+        IPX_GLDS(gb, la + HSTAGE_A);
+        if constexpr (QP == 2) IPX_GLDS(gb + WCfg<QP>::PART_B, la + HSTAGE_A + WCfg<QP>::PART_B);
+    }
+};
+
+__device__ __forceinline__ void w16_wait4(f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
+}
+__device__ __forceinline__ void w16_wait2(f32x4& b0, f32x4& b1) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1) :: "memory");
+}
+#define IPX_W16_MFMA4(A0_, A1_, B0_, B1_)                                                                             \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A0_), as_bf16x8(B0_), acc[0][0], 0, 0, 0);          \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A0_), as_bf16x8(B1_), acc[0][1], 0, 0, 0);          \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A1_), as_bf16x8(B0_), acc[1][0], 0, 0, 0);          \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A1_), as_bf16x8(B1_), acc[1][1], 0, 0, 0)
+
+template <int QP>
+__global__ void __launch_bounds__(1024)
+scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
+    using C = WCfg<QP>;
+    constexpr int BQ_ = 256, NBUF = C::NBUF, STAGE = C::STAGE, LOADS = C::LOADS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int scratch_bytes = nsortwaves * p.cap * 8;
+    const int stage_region = scratch_bytes > C::RING ? scratch_bytes : C::RING;
+    int* cnts = (int*)(smem + stage_region);
+    float* taus = (float*)(smem + stage_region + BQ_ * 4);
+    int* flags = (int*)(smem + stage_region + 2 * BQ_ * 4);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wd = wave & 3, wq = wave >> 2;             // 4 x 4 waves: 64 docs x 64 queries each
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = logical / p.S, split = logical - qb * p.S;
+
+    if (tid < BQ_) {
+        cnts[tid] = 0;
+        taus[tid] = ((int64_t)qb * BQ_ + tid < p.nq) ? -FLT_MAX : INFINITY;
+    }
+    if (tid < 2) flags[tid] = 0;
+    uint32_t* mypub = p.S > 1 ? p.pub + ((size_t)qb * p.S + split) * BQ_ : nullptr;
+    const int fill_limit = p.cap - 2 * HBD;
+
+    uint64_t* myqueues = p.cand + (size_t)blockIdx.x * BQ_ * p.cap;
+    uint64_t* scratch = (uint64_t*)smem + (size_t)wave * p.cap;
+
+    const int sw = (lane >> 2) & 3;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t a_off = (wd * 64 + l31) * 64;
+    const uint32_t b_off = HSTAGE_A + (wq * 64 + l31) * 64;
+    const uint32_t pc0 = ((0 + h) ^ sw) * 16, pc1 = ((2 + h) ^ sw) * 16;
+
+    // runs of R tiles dealt round-robin (split s: runs s, s + S, ...); a walker is a position in that
+    // sequence of stages: w0 = the stage being computed (ring slot `slot`), wi = the next stage to copy
+    const int R = p.run_tiles;
+    struct Walker { int t, ks, end, run; bool ok; };
+    auto advance = [&](Walker& w) {
+        if (!w.ok) return;
+        if (w.ks + 1 < p.nks) { ++w.ks; return; }
+        if (w.t + 1 < w.end) { ++w.t; w.ks = 0; return; }
+        const int64_t next = (int64_t)(w.run + p.S) * R;
+        if (next < p.ntiles) {
+            w.run += p.S;
+            w.t = (int)next;
+            w.end = w.t + R < p.ntiles ? w.t + R : p.ntiles;
+            w.ks = 0;
+            return;
+        }
+        w.ok = false;          // stays on its last stage: the dummy copies go to a slot nobody reads
+    };
+    Walker w0{split * R, 0, (split + 1) * R < p.ntiles ? (split + 1) * R : p.ntiles, split, split * R < p.ntiles};
+    if (!w0.ok) w0.t = 0;
+    Walker wi = w0;
+#pragma unroll 1
+    for (int i = 0; i < NBUF; ++i) {
+        WPieces<QP>(p, smem + i * STAGE, wi.t, qb, wi.ks, wave, lane).issue_all();
+        advance(wi);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 1)) : "memory");
+    __syncthreads();
+
+    int slot = 0, tiles_done = 0;
+    f32x4 a0, a1, b0, b1, c0, c1;
+    while (w0.ok) {
+        const int t = w0.t;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int ks = 0; ks < p.nks; ++ks) {
+            const uint32_t buf = smem_base + slot * STAGE;
+            const int nslot = slot + 1 == NBUF ? 0 : slot + 1;
+            // (Reading the next operand set under the current MFMAs — the 8-wave kernel's in-wave software
+            // pipeline — was measured here too: 97 ms against 93 ms for this plain order on the 8.8M-row
+            // workload; with four waves per SIMD the other waves already cover the read latency.)
+            // first 16 features of the stage
+            IPX_DS_READ_B128(a0, buf + a_off + pc0, 0); IPX_DS_READ_B128(a1, buf + a_off + pc0, 2048);
+            IPX_DS_READ_B128(b0, buf + b_off + pc0, 0); IPX_DS_READ_B128(b1, buf + b_off + pc0, 2048);
+            if constexpr (QP == 2) {
+                IPX_DS_READ_B128(c0, buf + b_off + C::PART_B + pc0, 0); IPX_DS_READ_B128(c1, buf + b_off + C::PART_B + pc0, 2048);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
+                IPX_W16_MFMA4(a0, a1, b0, b1);
+                w16_wait2(c0, c1);
+                IPX_W16_MFMA4(a0, a1, c0, c1);
+            } else {
+                w16_wait4(a0, a1, b0, b1);
+                IPX_W16_MFMA4(a0, a1, b0, b1);
+            }
+            asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+            // last 16 features
+            IPX_DS_READ_B128(a0, buf + a_off + pc1, 0); IPX_DS_READ_B128(a1, buf + a_off + pc1, 2048);
+            IPX_DS_READ_B128(b0, buf + b_off + pc1, 0); IPX_DS_READ_B128(b1, buf + b_off + pc1, 2048);
+            if constexpr (QP == 2) {
+                IPX_DS_READ_B128(c0, buf + b_off + C::PART_B + pc1, 0); IPX_DS_READ_B128(c1, buf + b_off + C::PART_B + pc1, 2048);
+            }
+            const WPieces<QP> sp(p, smem + slot * STAGE, wi.t, qb, wi.ks, wave, lane);
+            if constexpr (QP == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1) :: "memory");
+            else w16_wait4(a0, a1, b0, b1);
+            // this wave's last reads of the slot are in registers; its pieces of the next stage have landed
+            // (NBUF - 2 younger stages may be in flight); after the barrier both hold for all 16 waves
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            sp.issue_all();
+            IPX_W16_MFMA4(a0, a1, b0, b1);
+            if constexpr (QP == 2) { IPX_W16_MFMA4(a0, a1, c0, c1); }
+            asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+            advance(wi);
+            advance(w0);
+            slot = nslot;
+        }
+
+        // ---- epilogue: threshold filter, rare append to the per-query queues ----
+        ++tiles_done;
+        const int docbase = t * HBD + wd * 64 + 4 * h;
+        bool episode = lds_read_i32_nodma(&flags[(tiles_done + 1) & 1]) != 0;
+        int* myflag = &flags[tiles_done & 1];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ql = wq * 64 + j * 32 + l31;
+            const float tau = lds_read_f32_nodma(&taus[ql]);
+            float m = acc[0][j][0];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+            if (__any(m > tau)) {
+                uint64_t* qu = myqueues + (size_t)ql * p.cap;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float sc = acc[i][j][r];
+                        if (__any(sc > tau)) {
+                            const int64_t doc = docbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                            if (sc > tau && doc < p.N) {
+                                const int pos = lds_atomic_inc_nodma(&cnts[ql]);
+                                if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
+                                else *p.err = 1;
+                                if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
+                            }
+                        }
+                    }
+            }
+        }
+        episode = episode || is_pow4(tiles_done);
+        if (episode) {
+            // the selection scratch aliases the stage ring: let every copy land, compact, fetch the NBUF stages again
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid < 2) flags[tid] = 0;
+            if (wave < nsortwaves)
+                for (int ql = wave; ql < BQ_; ql += nsortwaves)
+                    compact_query_select(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
+                                         mypub ? mypub + ql : nullptr);
+            __syncthreads();
+            if (tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
+            Walker wr = w0;
+#pragma unroll 1
+            for (int i = 0; i < NBUF; ++i) {
+                const int sl = slot + i < NBUF ? slot + i : slot + i - NBUF;
+                WPieces<QP>(p, smem + sl * STAGE, wr.t, qb, wr.ks, wave, lane).issue_all();
+                advance(wr);
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 1)) : "memory");
+            __syncthreads();
+        } else if ((tiles_done & 1) == 0 && is_pow4(tiles_done >> 1)) {
+            if (tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave < nsortwaves)
+        for (int ql = wave; ql < BQ_; ql += nsortwaves) {
+            const int64_t qglobal = (int64_t)qb * BQ_ + ql;
+            if (qglobal < p.nq)
+                compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, true, qglobal, split, nullptr);
+        }
+}
+#undef IPX_W16_MFMA4
+
+}  // namespace ipx

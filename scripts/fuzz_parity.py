@@ -74,9 +74,11 @@ for c in range(cases):
     if storage != "bf16":
         variants += [("f32 large", {"f32_scan": 1, "no_small_batch": 1}), ("f32 small", {"f32_scan": 1, "small_f32_limit": 100000})]
     if storage != "f32":
-        variants += [("bf16 large", {"no_small_batch": 1}), ("bf16 parts 1", {"query_parts": 1}), ("bf16 parts 2", {"query_parts": 2})]
+        variants += [("bf16 large", {"no_small_batch": 1}), ("bf16 parts 1", {"query_parts": 1}), ("bf16 parts 2", {"query_parts": 2}),
+                     ("bf16 8 waves", {"no_small_batch": 1, "bf16_waves": 8, "query_parts": int(rng.choice([1, 2]))}),
+                     ("bf16 16 waves", {"no_small_batch": 1, "bf16_waves": 16, "query_parts": int(rng.choice([1, 2]))})]
     for name, params in variants:
-        for key in ("f32_scan", "no_small_batch", "query_parts"):
+        for key in ("f32_scan", "no_small_batch", "query_parts", "bf16_waves"):
             ix.set_param(key, 0)
         ix.set_param("small_f32_limit", 192)
         for key, val in params.items():
