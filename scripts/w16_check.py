@@ -2,6 +2,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from mural_amd import _lib as _l
+if os.environ.get('IPX_LIB'):
+    _l.LIB_PATH = os.path.join(os.path.dirname(_l.LIB_PATH), os.environ['IPX_LIB'])
 from mural_amd.faiss_retriever.retriever import FlatIPIndex
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 8_800_000
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 6980
@@ -13,7 +16,7 @@ for lo in range(0, rows, 400000):
     ix.add(torch.randn((min(400000, rows - lo), 768), generator=g, device=dev))
 Q = torch.randn((nq, 768), generator=g, device=dev)
 ix.set_timing(True)
-for k in (100, 1000):
+for k in [int(a) for a in os.environ.get('KS', '100,1000').split(',')]:
     res = {}
     for waves in (8, 16, 8, 16):
         ix.set_param("bf16_waves", waves)
