@@ -171,7 +171,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": 2.0 * nq * (hi - lo) * d / (sc2a * 1e-3) / 1e12,
                          "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": 2.0 * nq * (hi - lo) * d / (sc2a * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                         "kernel": "scan_bf16_kernel<4>"}}
+                         "kernel": "scan_bf16_w16_kernel<1>"}}
         # the reference's default depth (--depth 1000, src/pretrain_finetune1.sh:218-228): hi + lo query parts
         k_deep = 1000
         old_k = k
