@@ -243,7 +243,7 @@ def main():
                        "rescore_ms": round(bf["rescore_ms"], 3), "merge_ms": round(tm["merge_ms"], 3)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "kernel": "scan_bf16_kernel<4>" if is_bf16 else "scan_f32_kernel", "kernel_ms": scan_avg,
+                         "kernel": "scan_bf16_w16_kernel<1>" if is_bf16 else "scan_f32_kernel", "kernel_ms": scan_avg,
                          "flops_per_launch": flops_launch},
         }
         if sample is not None and world == 1:
