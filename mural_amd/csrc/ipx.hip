@@ -92,6 +92,7 @@ struct ipx_index {
     int force_kc = 0;        // 0 = automatic candidate count
     int query_parts = 0;     // 0 = automatic; 1 / 2 bf16 parts per query in the bf16 scan
     int small_f32_limit = 192;     // fp32 scans of up to this many queries take scan_f32_small_kernel
+    bool bf16_shape16 = false;     // 16-wave scan, one query part: v_mfma_f32_16x16x32_bf16 instead of 32x32x16
     int bf16_waves = 0;            // large-batch bf16 scan: 8 (scan_bf16_kernel<4>) or 16 waves (scan_bf16_w16_kernel); 0 = automatic
     bool no_small_batch = false;   // diagnostic: always use the 256-query bf16 scan variant
     bool force_f32_scan = false;   // storage 1: use the fp32 scan although a bf16 copy exists
@@ -519,7 +520,8 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
         const bool w16 = !small && (ix->bf16_waves == 16 || (ix->bf16_waves == 0 && qparts == 1));
         void (*kern)(const ipx::ScanParams, const int) =
             small ? (qparts == 2 ? ipx::scan_bf16_kernel<1, 2> : ipx::scan_bf16_kernel<1, 1>)
-            : w16 ? (qparts == 2 ? ipx::scan_bf16_w16_kernel<2> : ipx::scan_bf16_w16_kernel<1>)
+            : w16 ? (qparts == 2 ? ipx::scan_bf16_w16_kernel<2, false>
+                                 : (ix->bf16_shape16 ? ipx::scan_bf16_w16_kernel<1, true> : ipx::scan_bf16_w16_kernel<1, false>))
                   : (qparts == 2 ? ipx::scan_bf16_kernel<4, 2> : ipx::scan_bf16_kernel<4, 1>);
         IPX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(kern, dim3(G), dim3(w16 ? 1024 : ipx::HTHREADS), lds, st, p, nsortwaves);
@@ -1040,6 +1042,10 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
             return fail(IPX_ERR_STATE, "set_param: storage can only be chosen while the index is empty and unreserved");
         if (value != 0 && ix->d > 8192) return fail(IPX_ERR_ARG, "set_param: bf16 storage needs d <= 8192");
         ix->storage = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "bf16_shape16")) {
+        ix->bf16_shape16 = value != 0;
         return 0;
     }
     if (!strcmp(name, "bf16_waves")) {

@@ -48,9 +48,10 @@ __device__ __forceinline__ void w16_wait2(f32x4& b0, f32x4& b1) {
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A1_), as_bf16x8(B0_), acc[1][0], 0, 0, 0);          \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A1_), as_bf16x8(B1_), acc[1][1], 0, 0, 0)
 
-template <int QP>
+template <int QP, bool S16>
 __global__ void __launch_bounds__(1024)
 scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
+    static_assert(!S16 || QP == 1, "the 16x16x32 variant exists for one query part");
     using C = WCfg<QP>;
     constexpr int BQ_ = 256, NBUF = C::NBUF, STAGE = C::STAGE, LOADS = C::LOADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,88 +119,169 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
     f32x4 a0, a1, b0, b1, c0, c1;
     while (w0.ok) {
         const int t = w0.t;
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-        for (int ks = 0; ks < p.nks; ++ks) {
-            const uint32_t buf = smem_base + slot * STAGE;
-            const int nslot = slot + 1 == NBUF ? 0 : slot + 1;
-            // (Reading the next operand set under the current MFMAs — the 8-wave kernel's in-wave software
-            // pipeline — was measured here too: 97 ms against 93 ms for this plain order on the 8.8M-row
-            // workload; with four waves per SIMD the other waves already cover the read latency.)
-            // first 16 features of the stage
-            IPX_DS_READ_B128(a0, buf + a_off + pc0, 0); IPX_DS_READ_B128(a1, buf + a_off + pc0, 2048);
-            IPX_DS_READ_B128(b0, buf + b_off + pc0, 0); IPX_DS_READ_B128(b1, buf + b_off + pc0, 2048);
-            if constexpr (QP == 2) {
-                IPX_DS_READ_B128(c0, buf + b_off + C::PART_B + pc0, 0); IPX_DS_READ_B128(c1, buf + b_off + C::PART_B + pc0, 2048);
-                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
-                IPX_W16_MFMA4(a0, a1, b0, b1);
-                w16_wait2(c0, c1);
-                IPX_W16_MFMA4(a0, a1, c0, c1);
-            } else {
-                w16_wait4(a0, a1, b0, b1);
-                IPX_W16_MFMA4(a0, a1, b0, b1);
-            }
-            asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
-            // last 16 features
-            IPX_DS_READ_B128(a0, buf + a_off + pc1, 0); IPX_DS_READ_B128(a1, buf + a_off + pc1, 2048);
-            IPX_DS_READ_B128(b0, buf + b_off + pc1, 0); IPX_DS_READ_B128(b1, buf + b_off + pc1, 2048);
-            if constexpr (QP == 2) {
-                IPX_DS_READ_B128(c0, buf + b_off + C::PART_B + pc1, 0); IPX_DS_READ_B128(c1, buf + b_off + C::PART_B + pc1, 2048);
-            }
-            const WPieces<QP> sp(p, smem + slot * STAGE, wi.t, qb, wi.ks, wave, lane);
-            if constexpr (QP == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1) :: "memory");
-            else w16_wait4(a0, a1, b0, b1);
-            // this wave's last reads of the slot are in registers; its pieces of the next stage have landed
-            // (NBUF - 2 younger stages may be in flight); after the barrier both hold for all 16 waves
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            sp.issue_all();
-            IPX_W16_MFMA4(a0, a1, b0, b1);
-            if constexpr (QP == 2) { IPX_W16_MFMA4(a0, a1, c0, c1); }
-            asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
-            advance(wi);
-            advance(w0);
-            slot = nslot;
-        }
-
-        // ---- epilogue: threshold filter, rare append to the per-query queues ----
-        ++tiles_done;
-        const int docbase = t * HBD + wd * 64 + 4 * h;
-        bool episode = lds_read_i32_nodma(&flags[(tiles_done + 1) & 1]) != 0;
-        int* myflag = &flags[tiles_done & 1];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ql = wq * 64 + j * 32 + l31;
-            const float tau = lds_read_f32_nodma(&taus[ql]);
-            float m = acc[0][j][0];
-#pragma unroll
+        bool episode;
+        if constexpr (!S16) {
+            f32x16 acc[2][2];
+    #pragma unroll
             for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
-            if (__any(m > tau)) {
-                uint64_t* qu = myqueues + (size_t)ql * p.cap;
-#pragma unroll
+    #pragma unroll
+                for (int j = 0; j < 2; ++j)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+            for (int ks = 0; ks < p.nks; ++ks) {
+                const uint32_t buf = smem_base + slot * STAGE;
+                const int nslot = slot + 1 == NBUF ? 0 : slot + 1;
+                // (Reading the next operand set under the current MFMAs — the 8-wave kernel's in-wave software
+                // pipeline — was measured here too: 97 ms against 93 ms for this plain order on the 8.8M-row
+                // workload; with four waves per SIMD the other waves already cover the read latency.)
+                // first 16 features of the stage
+                IPX_DS_READ_B128(a0, buf + a_off + pc0, 0); IPX_DS_READ_B128(a1, buf + a_off + pc0, 2048);
+                IPX_DS_READ_B128(b0, buf + b_off + pc0, 0); IPX_DS_READ_B128(b1, buf + b_off + pc0, 2048);
+                if constexpr (QP == 2) {
+                    IPX_DS_READ_B128(c0, buf + b_off + C::PART_B + pc0, 0); IPX_DS_READ_B128(c1, buf + b_off + C::PART_B + pc0, 2048);
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
+                    IPX_W16_MFMA4(a0, a1, b0, b1);
+                    w16_wait2(c0, c1);
+                    IPX_W16_MFMA4(a0, a1, c0, c1);
+                } else {
+                    w16_wait4(a0, a1, b0, b1);
+                    IPX_W16_MFMA4(a0, a1, b0, b1);
+                }
+                asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+                // last 16 features
+                IPX_DS_READ_B128(a0, buf + a_off + pc1, 0); IPX_DS_READ_B128(a1, buf + a_off + pc1, 2048);
+                IPX_DS_READ_B128(b0, buf + b_off + pc1, 0); IPX_DS_READ_B128(b1, buf + b_off + pc1, 2048);
+                if constexpr (QP == 2) {
+                    IPX_DS_READ_B128(c0, buf + b_off + C::PART_B + pc1, 0); IPX_DS_READ_B128(c1, buf + b_off + C::PART_B + pc1, 2048);
+                }
+                const WPieces<QP> sp(p, smem + slot * STAGE, wi.t, qb, wi.ks, wave, lane);
+                if constexpr (QP == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1) :: "memory");
+                else w16_wait4(a0, a1, b0, b1);
+                // this wave's last reads of the slot are in registers; its pieces of the next stage have landed
+                // (NBUF - 2 younger stages may be in flight); after the barrier both hold for all 16 waves
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                sp.issue_all();
+                IPX_W16_MFMA4(a0, a1, b0, b1);
+                if constexpr (QP == 2) { IPX_W16_MFMA4(a0, a1, c0, c1); }
+                asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+                advance(wi);
+                advance(w0);
+                slot = nslot;
+            }
+
+            // ---- epilogue: threshold filter, rare append to the per-query queues ----
+            ++tiles_done;
+            const int docbase = t * HBD + wd * 64 + 4 * h;
+            episode = lds_read_i32_nodma(&flags[(tiles_done + 1) & 1]) != 0;
+            int* myflag = &flags[tiles_done & 1];
+    #pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ql = wq * 64 + j * 32 + l31;
+                const float tau = lds_read_f32_nodma(&taus[ql]);
+                float m = acc[0][j][0];
+    #pragma unroll
                 for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float sc = acc[i][j][r];
-                        if (__any(sc > tau)) {
-                            const int64_t doc = docbase + i * 32 + (r & 3) + 8 * (r >> 2);
-                            if (sc > tau && doc < p.N) {
-                                const int pos = lds_atomic_inc_nodma(&cnts[ql]);
-                                if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
-                                else *p.err = 1;
-                                if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+                if (__any(m > tau)) {
+                    uint64_t* qu = myqueues + (size_t)ql * p.cap;
+    #pragma unroll
+                    for (int i = 0; i < 2; ++i)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float sc = acc[i][j][r];
+                            if (__any(sc > tau)) {
+                                const int64_t doc = docbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                                if (sc > tau && doc < p.N) {
+                                    const int pos = lds_atomic_inc_nodma(&cnts[ql]);
+                                    if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
+                                    else *p.err = 1;
+                                    if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
+                                }
                             }
                         }
-                    }
+                }
+            }
+        } else {
+            // v_mfma_f32_16x16x32_bf16: one MFMA covers a whole K-stage (32 features) of a 16 x 16 tile; the
+            // wave's 64 x 64 corner is 4 x 4 of them. Same flops per cycle as the 32x32x16 form on paper, but
+            // the chip sustains a higher clock on it (MI355X_MICROARCH.md: ~1.15x the FLOP/s in bare loops).
+            // Lane (r = l & 15, g = l >> 4) holds features 8g .. 8g+7 of row r: 16-byte chunk g of the row's
+            // 64-byte stage line, swizzled as packed.
+            f32x4 acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int r15 = lane & 15, g4 = lane >> 4;
+            const uint32_t chunk = (uint32_t)((g4 ^ ((r15 >> 2) & 3)) * 16);
+            const uint32_t a16 = (wd * 64 + r15) * 64 + chunk;
+            const uint32_t b16 = HSTAGE_A + (wq * 64 + r15) * 64 + chunk;
+            f32x4 x0, x1, x2, x3;
+#define IPX_W16_ROW(J_, B_)                                                                                              \
+            acc[0][J_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x0), as_bf16x8(B_), acc[0][J_], 0, 0, 0);     \
+            acc[1][J_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x1), as_bf16x8(B_), acc[1][J_], 0, 0, 0);     \
+            acc[2][J_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x2), as_bf16x8(B_), acc[2][J_], 0, 0, 0);     \
+            acc[3][J_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x3), as_bf16x8(B_), acc[3][J_], 0, 0, 0)
+            for (int ks = 0; ks < p.nks; ++ks) {
+                const uint32_t buf = smem_base + slot * STAGE;
+                const int nslot = slot + 1 == NBUF ? 0 : slot + 1;
+                IPX_DS_READ_B128(x0, buf + a16, 0); IPX_DS_READ_B128(x1, buf + a16, 1024);
+                IPX_DS_READ_B128(x2, buf + a16, 2048); IPX_DS_READ_B128(x3, buf + a16, 3072);
+                IPX_DS_READ_B128(b0, buf + b16, 0); IPX_DS_READ_B128(b1, buf + b16, 1024);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(b0), "+v"(b1) :: "memory");
+                IPX_W16_ROW(0, b0);
+                IPX_W16_ROW(1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                IPX_DS_READ_B128(b0, buf + b16, 2048); IPX_DS_READ_B128(b1, buf + b16, 3072);
+                const WPieces<QP> sp(p, smem + slot * STAGE, wi.t, qb, wi.ks, wave, lane);
+                w16_wait2(b0, b1);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                sp.issue_all();
+                IPX_W16_ROW(2, b0);
+                IPX_W16_ROW(3, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                advance(wi);
+                advance(w0);
+                slot = nslot;
+            }
+#undef IPX_W16_ROW
+            ++tiles_done;
+            const int docbase = t * HBD + wd * 64 + 4 * g4;
+            episode = lds_read_i32_nodma(&flags[(tiles_done + 1) & 1]) != 0;
+            int* myflag = &flags[tiles_done & 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ql = wq * 64 + j * 16 + r15;
+                const float tau = lds_read_f32_nodma(&taus[ql]);
+                float m = acc[0][j][0];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[i][j][r]);
+                if (__any(m > tau)) {
+                    uint64_t* qu = myqueues + (size_t)ql * p.cap;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float sc = acc[i][j][r];
+                            if (__any(sc > tau)) {
+                                const int64_t doc = docbase + i * 16 + r;
+                                if (sc > tau && doc < p.N) {
+                                    const int pos = lds_atomic_inc_nodma(&cnts[ql]);
+                                    if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
+                                    else *p.err = 1;
+                                    if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
+                                }
+                            }
+                        }
+                }
             }
         }
         episode = episode || is_pow4(tiles_done);

@@ -18,8 +18,9 @@ Q = torch.randn((nq, 768), generator=g, device=dev)
 ix.set_timing(True)
 for k in [int(a) for a in os.environ.get('KS', '100,1000').split(',')]:
     res = {}
-    for waves in (8, 16, 8, 16):
-        ix.set_param("bf16_waves", waves)
+    for waves in (8, 16, 116, 8, 16, 116):          # 116 = 16 waves with the 16x16x32 MFMA shape (one query part)
+        ix.set_param("bf16_waves", waves % 100)
+        ix.set_param("bf16_shape16", waves // 100)
         ts = []
         for it in range(3):
             D, I = ix.search_device(Q, k); torch.cuda.synchronize()
@@ -29,4 +30,4 @@ for k in [int(a) for a in os.environ.get('KS', '100,1000').split(',')]:
             assert torch.equal(res[waves][0], D) and torch.equal(res[waves][1], I)
         res[waves] = (D, I)
         print(f"k {k} waves {waves}: scan {min(ts):.2f} ms ({2*rows*nq*768/min(ts)/1e9:.0f} TFLOP/s) candidates {st['candidates']} repeated {st['fallback_queries']}", flush=True)
-    print("  same bits:", bool(torch.equal(res[8][0], res[16][0]) and torch.equal(res[8][1], res[16][1])), flush=True)
+    print("  same bits:", all(bool(torch.equal(res[8][0], res[w][0]) and torch.equal(res[8][1], res[w][1])) for w in res), flush=True)
