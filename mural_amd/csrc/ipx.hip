@@ -639,9 +639,13 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     // Batches of up to 64 queries are bound by the corpus stream, not the matrix core: the second
     // query part is free there, and its short list (<= the number of splits) lets every split
     // publish just its best score (scan_bf16_kernel, fast1).
+    // Measured on the 8.8M x 768 Gaussian workload, storage 1, large batches: one part with 3k candidates
+    // beats two parts with 2k (k = 500: 129 vs 190 ms; k = 700 with 2048: 154 vs 199 ms, nothing repeated;
+    // at 2.1k every query was) — so one part as long as 3.2k fits the longest list, its list 5k capped there.
     const int mult1 = ix->storage == 2 ? 2 : 5;
     const bool small = nq <= 64 && !ix->no_small_batch;
-    int qparts = ix->query_parts > 0 ? ix->query_parts : ((small || mult1 * k > 1024) ? 2 : 1);
+    const bool one_part_fits = ix->storage == 2 ? 2 * k <= 1024 : 16 * k <= 5 * (int)IPX_MAX_K;
+    int qparts = ix->query_parts > 0 ? ix->query_parts : ((small || !one_part_fits) ? 2 : 1);
     int kc = ix->force_kc > 0 ? ix->force_kc
              : qparts == 1 ? std::max(256, mult1 * k)
                            : std::max(256, ix->storage == 2 ? k + k / 4 : 2 * k);
