@@ -648,7 +648,11 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     int qparts = ix->query_parts > 0 ? ix->query_parts : ((small || !one_part_fits) ? 2 : 1);
     int kc = ix->force_kc > 0 ? ix->force_kc
              : qparts == 1 ? std::max(256, mult1 * k)
-                           : std::max(256, ix->storage == 2 ? k + k / 4 : 2 * k);
+             : ix->storage == 2 ? std::max(256, k + k / 4)
+             // two parts, fp32 rows: 2k candidates, 3k for shallow lists (measured, small batches: at k = 150 a
+             // list of 300 left 2 of 32 queries to the repeat pass, 450 none; from k = 250 on 2k leaves none);
+             // 256 (the number of splits: every split publishes just its best score) while that is >= 2.5k
+                           : std::max(256, 5 * k <= 2 * 256 ? 256 : (k <= 256 ? 3 * k : 2 * k));
     kc = std::min(std::max(kc, k), (int)IPX_MAX_K);
 
     const float* qf = dq;
