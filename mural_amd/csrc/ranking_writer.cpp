@@ -15,9 +15,12 @@
 #include <charconv>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <functional>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -141,38 +144,53 @@ extern "C" int ipx_write_ranking(const char* path, const uint32_t* qids, int qid
         return IPX_ERR_IO;
     }
     const size_t line_max = 4 * (size_t)qid_width + (docids ? 4 * (size_t)docid_width : 24) + 48;
-    const size_t flush_at = 1u << 22;
-    std::vector<char> buf(flush_at + line_max * (size_t)(k > 0 ? k : 1) + 64);
-    std::vector<int> order(k);
-    size_t used = 0;
+    // Queries are formatted in blocks by a few threads (sorting + shortest-round-trip float printing is
+    // the cost: 7M lines at depth 1000), and the blocks are written in order by this thread.
+    const int64_t block = std::max<int64_t>(1, std::min<int64_t>(256, (int64_t)((4u << 20) / (line_max * (size_t)(k > 0 ? k : 1) + 1))));
+    int nthreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    if (const char* e = std::getenv("IPX_WRITER_THREADS")) nthreads = std::max(1, std::min(64, std::atoi(e)));
+    auto format_block = [&](int64_t q0, int64_t q1, std::vector<char>& out) {
+        out.resize((size_t)(q1 - q0) * line_max * (size_t)(k > 0 ? k : 1) + 64);
+        std::vector<int> order(k);
+        char* p = out.data();
+        for (int64_t i = q0; i < q1; ++i) {
+            const float* s = scores + i * k;
+            std::iota(order.begin(), order.end(), 0);
+            // stable, descending by score only (ties keep input order, as Python's sorted does)
+            std::stable_sort(order.begin(), order.end(), [s](int a, int b) {
+                const float x = std::isnan(s[a]) ? -INFINITY : s[a];
+                const float y = std::isnan(s[b]) ? -INFINITY : s[b];
+                return x > y;
+            });
+            for (int j = 0; j < k; ++j) {
+                const int h = order[j];
+                p = put_ucs4(p, qids + i * qid_width, qid_width);
+                *p++ = '\t';
+                if (docids) p = put_ucs4(p, docids + ((size_t)i * k + h) * docid_width, docid_width);
+                else p = put_i64(p, docids_i64[(size_t)i * k + h]);
+                *p++ = '\t';
+                p += py_float_repr((double)s[h], p);
+                *p++ = '\n';
+            }
+        }
+        out.resize((size_t)(p - out.data()));
+    };
+    std::vector<std::vector<char>> bufs((size_t)nthreads);
     bool ok = true;
-    for (int64_t i = 0; i < nq && ok; ++i) {
-        const float* s = scores + i * k;
-        std::iota(order.begin(), order.end(), 0);
-        // stable, descending by score only (ties keep input order, as Python's sorted does)
-        std::stable_sort(order.begin(), order.end(), [s](int a, int b) {
-            const float x = std::isnan(s[a]) ? -INFINITY : s[a];
-            const float y = std::isnan(s[b]) ? -INFINITY : s[b];
-            return x > y;
-        });
-        char* p = buf.data() + used;
-        for (int j = 0; j < k; ++j) {
-            const int h = order[j];
-            p = put_ucs4(p, qids + i * qid_width, qid_width);
-            *p++ = '\t';
-            if (docids) p = put_ucs4(p, docids + ((size_t)i * k + h) * docid_width, docid_width);
-            else p = put_i64(p, docids_i64[(size_t)i * k + h]);
-            *p++ = '\t';
-            p += py_float_repr((double)s[h], p);
-            *p++ = '\n';
+    for (int64_t q0 = 0; q0 < nq && ok; q0 += block * nthreads) {
+        std::vector<std::thread> th;
+        int used_bufs = 0;
+        for (int t = 0; t < nthreads; ++t) {
+            const int64_t b0 = q0 + t * block, b1 = std::min(nq, b0 + block);
+            if (b0 >= nq) break;
+            ++used_bufs;
+            if (nthreads == 1 || nq <= block) format_block(b0, b1, bufs[(size_t)t]);
+            else th.emplace_back(format_block, b0, b1, std::ref(bufs[(size_t)t]));
         }
-        used = p - buf.data();
-        if (used >= flush_at) {
-            ok = fwrite(buf.data(), 1, used, f) == used;
-            used = 0;
-        }
+        for (auto& t : th) t.join();
+        for (int t = 0; t < used_bufs && ok; ++t)
+            ok = bufs[(size_t)t].empty() || fwrite(bufs[(size_t)t].data(), 1, bufs[(size_t)t].size(), f) == bufs[(size_t)t].size();
     }
-    if (ok && used) ok = fwrite(buf.data(), 1, used, f) == used;
     if (fclose(f) != 0) ok = false;
     if (!ok) {
         ipx_set_error_((std::string("write_ranking: write failed on ") + path).c_str());
