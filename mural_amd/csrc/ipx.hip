@@ -253,7 +253,8 @@ int scan_f32_small_path(ipx_index* ix, const float* dq, const float* dw, int A, 
         if (int rc = ix->flags.ensure((size_t)nq * sizeof(int))) return rc;
     }
     const size_t ctr_bytes = ((size_t)nqb * sizeof(uint32_t) + 255) / 256 * 256;
-    const size_t pub_bytes = ctr_bytes + (size_t)G * bq * sizeof(uint32_t);
+    // published bounds: up to IPX_MAX_SUBSPLITS values per split and query (short-list path)
+    const size_t pub_bytes = ctr_bytes + (size_t)G * bq * ipx::IPX_MAX_SUBSPLITS * sizeof(uint32_t);
     if (int rc = ix->pub.ensure(pub_bytes)) return rc;
     IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
 
@@ -480,7 +481,8 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
         if (int rc = ix->partI.ensure(ncand * S * sizeof(int64_t))) return rc;
     }
     const size_t ctr_bytes = ((size_t)nqb * sizeof(uint32_t) + 255) / 256 * 256;
-    const size_t pub_bytes = ctr_bytes + (size_t)G * bq * sizeof(uint32_t);
+    // published bounds: up to 4 values per split and query on the small-batch short-list path
+    const size_t pub_bytes = ctr_bytes + (size_t)G * bq * (small ? 4 : 1) * sizeof(uint32_t);
     if (int rc = ix->pub.ensure(pub_bytes)) return rc;
     IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
 

@@ -343,18 +343,24 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
         taus[tid] = ((int64_t)qb * BQ_ + tid < p.nq) ? -FLT_MAX : INFINITY;
     }
     if (tid < 2) flags[tid] = 0;
-    uint32_t* mypub = p.S > 1 ? p.pub + ((size_t)qb * p.S + split) * BQ_ : nullptr;
     const int fill_limit = p.cap - 2 * HBD;
-    // Small batches with at least as many splits as candidates (r == 1: every split publishes its
-    // single best score): the best score per query is kept by an LDS max beside the appends and
-    // published / polled at 1, 2, 4, 8, ... tiles without touching the queues — no compaction
-    // episodes at all unless a queue fills. (Each split sees only N / S rows, so its own k-th best
-    // is a poor threshold anyway; the union bound is the one that prunes.)
-    uint32_t* best = (uint32_t*)(flags + 4);              // [BQ_]   (QW == 1 only)
-    uint32_t* tmin = best + BQ_;                          // [BQ_]
-    const bool fast1 = QW == 1 && p.S > 1 && p.r == 1;
-    if (QW == 1 && tid < BQ_) best[tid] = 0;
-
+    // Small batches with short lists (candidates <= 4 S): no compaction episodes unless a queue fills.
+    // Each split deals its tiles round-robin to r = ceil(candidates / S) sub-splits and keeps the best
+    // score of each by an LDS max beside the appends; the S r bests are published / polled at r, 2r,
+    // 4r, ... tiles and every 32, and their minimum bounds the list's last score from below (S r
+    // disjoint sets of rows, each holding a row at or above it). With r == 1: every split publishes
+    // its best. (Each split sees only N / S rows, so its own k-th best is a poor threshold anyway;
+    // the union bound is the one that prunes.)
+    constexpr int MAXSUB = 4;
+    uint32_t* best = (uint32_t*)(flags + 4);              // [MAXSUB][BQ_]   (QW == 1 only)
+    uint32_t* tmin = best + MAXSUB * BQ_;                 // [BQ_]
+    const bool fast1 = QW == 1 && p.S > 1 && p.r <= MAXSUB;
+    const int rs = fast1 ? p.r : 1;                       // published values per split and query
+    uint32_t* mypub = p.S > 1 ? p.pub + ((size_t)qb * p.S + split) * rs * BQ_ : nullptr;
+    if (QW == 1 && tid < BQ_) {
+#pragma unroll
+        for (int u = 0; u < MAXSUB; ++u) best[u * BQ_ + tid] = 0;
+    }
     uint64_t* myqueues = p.cand + (size_t)blockIdx.x * BQ_ * p.cap;
     uint64_t* scratch = (uint64_t*)smem + (size_t)wave * p.cap;
 
@@ -537,6 +543,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
         const int docbase = t * HBD + wd * 64 + 4 * h;
         bool episode = lds_read_i32_nodma(&flags[(tiles_done + 1) & 1]) != 0;
         int* myflag = &flags[tiles_done & 1];
+        const int sub = fast1 ? (tiles_done - 1) % rs : 0;          // this tile's sub-split
 #pragma unroll
         for (int j = 0; j < QW; ++j) {
             const int ql = wq * (32 * QW) + j * 32 + l31;
@@ -560,7 +567,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
                                 if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
                                 else *p.err = 1;
                                 if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
-                                if constexpr (QW == 1) lds_atomic_max_u32_nodma(&best[ql], f32_ordered(sc));
+                                if constexpr (QW == 1) lds_atomic_max_u32_nodma(&best[sub * BQ_ + ql], f32_ordered(sc));
                                 ++tr_appends;
                             }
                         }
@@ -570,21 +577,23 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
         uint64_t tr_e1 = 0;
         if (p.trace) { tr_e1 = __builtin_readcyclecounter(); tr_epi += tr_e1 - tr_e0; }
         if constexpr (QW == 1) {
-            if (fast1 && ((tiles_done & (tiles_done - 1)) == 0 || (tiles_done & 31) == 0)) {
-                // publish this split's best, take the minimum over all splits as the new floor.
-                // After the first tile every split starts at the same time: wait (bounded) until
-                // all of them have published, so the second tile already runs against a bound.
+            const int rounds = tiles_done / rs;                    // completed rounds over the sub-splits
+            if (fast1 && tiles_done == rounds * rs && ((rounds & (rounds - 1)) == 0 || (tiles_done & 31) == 0)) {
+                // publish the sub-splits' bests, take the minimum over all splits as the new floor.
+                // After the first round every split is at the same point: wait (bounded) until all of
+                // them have published, so the next tile already runs against a bound.
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (tid < BQ_) {
-                    const uint32_t b = best[tid];
-                    if (b) __hip_atomic_store(mypub + tid, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int e = tid; e < rs * BQ_; e += HTHREADS) {
+                    const uint32_t b = best[e];
+                    if (b) __hip_atomic_store(mypub + e, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 const int q = tid & (BQ_ - 1), part = tid / BQ_;           // 8 threads per query
-                const int per = (p.S + 7) / 8;
-                const int s_lo = part * per, s_hi = s_lo + per < p.S ? s_lo + per : p.S;
-                const uint32_t* col = p.pub + (size_t)qb * p.S * BQ_ + q;
-                for (int attempt = 0; attempt < (tiles_done == 1 ? 64 : 1); ++attempt) {
+                const int nvals = p.S * rs;
+                const int per = (nvals + 7) / 8;
+                const int s_lo = part * per, s_hi = s_lo + per < nvals ? s_lo + per : nvals;
+                const uint32_t* col = p.pub + (size_t)qb * nvals * BQ_ + q;
+                for (int attempt = 0; attempt < (rounds == 1 ? 64 : 1); ++attempt) {
                     if (tid < BQ_) tmin[tid] = 0xffffffffu;
                     __syncthreads();
                     uint32_t v = 0xffffffffu;
@@ -621,11 +630,11 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             if (wave < nsortwaves)
                 for (int ql = wave; ql < BQ_; ql += nsortwaves)
                     compact_query_select(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
-                                         mypub ? mypub + ql : nullptr);
+                                         mypub && !fast1 ? mypub + ql : nullptr);
             if (p.trace) { tr_b = __builtin_readcyclecounter(); tr_own += tr_b - tr_a; }
             __syncthreads();
             if (p.trace) tr_w2 += __builtin_readcyclecounter() - tr_b;
-            if (tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
+            if (!fast1 && tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
 #pragma unroll
             for (int i = 0; i < NBUF; ++i) {
                 const int sl = slot + i < NBUF ? slot + i : slot + i - NBUF;
@@ -634,7 +643,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 1)) : "memory");
             __syncthreads();
             if (p.trace) tr_sort += __builtin_readcyclecounter() - tr_e1;
-        } else if ((tiles_done & 1) == 0 && is_pow4(tiles_done >> 1)) {
+        } else if (!fast1 && (tiles_done & 1) == 0 && is_pow4(tiles_done >> 1)) {
             if (tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
         }
     }

@@ -14,6 +14,8 @@
 
 namespace ipx {
 
+constexpr int IPX_MAX_SUBSPLITS = 4;    // short-list path of the small-batch scans: sub-splits per split
+
 template <int QT> struct SCfg {
     static constexpr int BQ_ = 32 * QT;                       // queries per workgroup
     static constexpr int THREADS = 512;
@@ -84,8 +86,8 @@ scan_f32_small_kernel(const ScanParams p, const int nsortwaves) {
     int* cnts = (int*)(smem + stage_region);
     float* taus = (float*)(smem + stage_region + BQ_ * 4);
     int* flags = (int*)(smem + stage_region + 2 * BQ_ * 4);
-    uint32_t* best = (uint32_t*)(flags + 4);              // [BQ_] best score of this split so far (ordered bits)
-    uint32_t* tmin = best + BQ_;                          // [BQ_]
+    uint32_t* best = (uint32_t*)(flags + 4);              // [IPX_MAX_SUBSPLITS][BQ_] best scores so far (ordered bits)
+    uint32_t* tmin = best + IPX_MAX_SUBSPLITS * BQ_;      // [BQ_]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,16 +102,19 @@ scan_f32_small_kernel(const ScanParams p, const int nsortwaves) {
     if (tid < BQ_) {
         cnts[tid] = 0;
         taus[tid] = ((int64_t)qb * BQ_ + tid < p.nq) ? -FLT_MAX : INFINITY;
-        best[tid] = 0;
+#pragma unroll
+        for (int u = 0; u < IPX_MAX_SUBSPLITS; ++u) best[u * BQ_ + tid] = 0;
     }
     if (tid < 2) flags[tid] = 0;
-    uint32_t* mypub = p.S > 1 ? p.pub + ((size_t)qb * p.S + split) * BQ_ : nullptr;
     const int fill_limit = p.cap - 4 * BD;      // a set flag is acted on one step (2 tiles) later
-    // r == 1 (at least as many splits as results wanted): every split publishes its single best
-    // score, kept by an LDS max beside the appends, at 1, 2, 4, ... steps and every 32 — the
-    // minimum over the splits bounds the k-th best of the index from below. No compaction episodes
-    // unless a queue fills.
-    const bool fast1 = p.S > 1 && p.r == 1;
+    // Short lists (k <= 4 S): no compaction episodes unless a queue fills. Each split deals its steps
+    // round-robin to r = ceil(k / S) sub-splits and keeps the best score of each by an LDS max beside
+    // the appends; the S r bests are published at r, 2r, 4r, ... steps and every 32, and their minimum
+    // bounds the k-th best score of the index from below (S r >= k disjoint sets of rows, each holding
+    // a row at or above it). With r == 1 this is "every split publishes its best".
+    const bool fast1 = p.S > 1 && p.r <= IPX_MAX_SUBSPLITS;
+    const int rs = fast1 ? p.r : 1;             // published values per split and query
+    uint32_t* mypub = p.S > 1 ? p.pub + ((size_t)qb * p.S + split) * rs * BQ_ : nullptr;
 
     uint64_t* myqueues = p.cand + (size_t)blockIdx.x * BQ_ * p.cap;
     uint64_t* scratch = (uint64_t*)smem + (size_t)wave * p.cap;
@@ -231,6 +236,7 @@ scan_f32_small_kernel(const ScanParams p, const int nsortwaves) {
         // barriers lie between those writes and this read; this step writes the other flag)
         bool episode = lds_read_i32_nodma(&flags[(tiles_done + 1) & 1]) != 0;
         int* myflag = &flags[tiles_done & 1];
+        const int sub = fast1 ? (tiles_done - 1) % rs : 0;          // this step's sub-split
 #pragma unroll
         for (int j = 0; j < QT; ++j) {
             const int ql = j * 32 + l31;
@@ -250,28 +256,30 @@ scan_f32_small_kernel(const ScanParams p, const int nsortwaves) {
                             if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
                             else *p.err = 1;
                             if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
-                            lds_atomic_max_u32_nodma(&best[ql], f32_ordered(sc));
+                            lds_atomic_max_u32_nodma(&best[sub * BQ_ + ql], f32_ordered(sc));
                         }
                     }
                 }
             }
         }
-        if (fast1 && ((tiles_done & (tiles_done - 1)) == 0 || (tiles_done & 31) == 0)) {
-            // publish this split's best, take the minimum over all splits as the new floor. After
-            // the first tile every split is at the same point: wait (bounded) until all of them
-            // have published, so the second tile already runs against a bound.
+        const int rounds = tiles_done / rs;                        // completed rounds over the sub-splits
+        if (fast1 && tiles_done == rounds * rs && ((rounds & (rounds - 1)) == 0 || (tiles_done & 31) == 0)) {
+            // publish the sub-splits' bests, take the minimum over all splits as the new floor. After
+            // the first round every split is at the same point: wait (bounded) until all of them
+            // have published, so the next step already runs against a bound.
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid < BQ_) {
-                const uint32_t b = best[tid];
-                if (b) __hip_atomic_store(mypub + tid, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int e = tid; e < rs * BQ_; e += THREADS) {
+                const uint32_t b = best[e];
+                if (b) __hip_atomic_store(mypub + e, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            constexpr int TPQ = THREADS / BQ_;                         // 8 threads per query
+            constexpr int TPQ = THREADS / BQ_;                         // threads per query
             const int q = tid & (BQ_ - 1), part = tid / BQ_;
-            const int per = (p.S + TPQ - 1) / TPQ;
-            const int s_lo = part * per, s_hi = s_lo + per < p.S ? s_lo + per : p.S;
-            const uint32_t* col = p.pub + (size_t)qb * p.S * BQ_ + q;
-            for (int attempt = 0; attempt < (tiles_done == 1 ? 64 : 1); ++attempt) {
+            const int nvals = p.S * rs;
+            const int per = (nvals + TPQ - 1) / TPQ;
+            const int s_lo = part * per, s_hi = s_lo + per < nvals ? s_lo + per : nvals;
+            const uint32_t* col = p.pub + (size_t)qb * nvals * BQ_ + q;
+            for (int attempt = 0; attempt < (rounds == 1 ? 64 : 1); ++attempt) {
                 if (tid < BQ_) tmin[tid] = 0xffffffffu;
                 __syncthreads();
                 uint32_t v = 0xffffffffu;
@@ -305,9 +313,9 @@ scan_f32_small_kernel(const ScanParams p, const int nsortwaves) {
             if (wave < nsortwaves)
                 for (int ql = wave; ql < BQ_; ql += nsortwaves)
                     compact_query_select(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
-                                         mypub ? mypub + ql : nullptr);
+                                         mypub && !fast1 ? mypub + ql : nullptr);
             __syncthreads();
-            if (tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
+            if (!fast1 && tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
             Walker wr = w0;
 #pragma unroll 1
             for (int i = 0; i < NBUF; ++i) {
