@@ -65,7 +65,24 @@ for c in range(cases):
         if not (np.array_equal(I, rI) and np.array_equal(D, rD)):
             print("SEARCH MISMATCH case", c, name, dict(n=n, d=d, q=q, k=k, A=A, base=base, storage=storage), flush=True)
             sys.exit(1)
-    del ix
+    # ---- MURAL pooler entry points: pool == oracle (tolerance), pooled add / search == pool then add / search (bits) ----
+    Ls = int(rng.integers(A + 1, A + 12)); begin = int(rng.integers(1, Ls - A + 1))
+    W = (rng.standard_normal((A, d)) * 0.5).astype(np.float32); bvec = rng.standard_normal(A).astype(np.float32)   # logits of a few units
+    Hp = rng.standard_normal((min(n, 700), Ls, d), dtype=np.float32); Hq = rng.standard_normal((q, Ls, d), dtype=np.float32)
+    px = FlatIPIndex(d, storage=storage)
+    rep_p, att_p = px.pool(Hp, W, bvec, begin_id=begin)
+    orep, oatt = O.mural_pool_att(Hp, W, bvec, begin)
+    if not (np.allclose(rep_p, orep, rtol=1e-5, atol=1e-5) and np.allclose(att_p, oatt, rtol=1e-5, atol=1e-6)):
+        print("POOL MISMATCH case", c, dict(d=d, A=A, Ls=Ls, begin=begin), "max |rep diff|", float(np.abs(rep_p - orep).max()),
+              "max |att diff|", float(np.abs(att_p - oatt).max()), "max |logit|", float(np.abs(Hp[:, 0] @ W.T + bvec).max()), flush=True); sys.exit(1)
+    px.add_pooled(Hp, W, bvec, begin_id=begin)
+    Dp, Ip = px.search_pooled(Hq, W, bvec, min(k, 200), begin_id=begin)
+    py = FlatIPIndex(d, storage=storage); py.add(rep_p)
+    rep_q, _ = py.pool(Hq, W, bvec, begin_id=begin)
+    Dy, Iy = py.search(rep_q, min(k, 200))
+    if not (np.array_equal(Dp, Dy) and np.array_equal(Ip, Iy)):
+        print("POOLED SEARCH MISMATCH case", c, dict(d=d, A=A, Ls=Ls, begin=begin, storage=storage), flush=True); sys.exit(1)
+    del ix, px, py
     if c % 20 == 19:
         print(f"{c + 1} cases ok, {time.time() - t0:.0f} s", flush=True)
 print("all", cases, "cases ok")
