@@ -93,6 +93,7 @@ struct ipx_index {
     int query_parts = 0;     // 0 = automatic; 1 / 2 bf16 parts per query in the bf16 scan
     int small_f32_limit = 192;     // fp32 scans of up to this many queries take scan_f32_small_kernel
     bool bf16_shape16 = false;     // 16-wave scan, one query part: v_mfma_f32_16x16x32_bf16 instead of 32x32x16
+    int f32_helpers = 8;           // fp32 large-tile scan: helper list slots per query block (0 = no work stealing)
     int run_tiles = 0;             // fp32 large-tile scan: corpus tiles per run of the dynamic split (0 = automatic)
     int bf16_waves = 0;            // large-batch bf16 scan: 8 (scan_bf16_kernel<4>) or 16 waves (scan_bf16_w16_kernel); 0 = automatic
     bool no_small_batch = false;   // diagnostic: always use the 256-query bf16 scan variant
@@ -287,6 +288,9 @@ int scan_f32_small_path(ipx_index* ix, const float* dq, const float* dw, int A, 
     p.k = k;
     p.cap = cap;
     p.S = S;
+    p.S_out = S;
+    p.helpers = 0;
+    p.help_ctr = nullptr;
     p.ntiles = ntiles;
     const int lds = std::max(ring, nsortwaves * cap * 8) + ipx::LDS_STATE_BYTES;
     {
@@ -356,16 +360,21 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
     S = std::min(S, nruns);
     const int G = nqb * S;
     const int cap = std::max(512, next_pow2(2 * k));
+    // spare list slots per query block for workgroups that finish their own block early (scan_f32_kernel)
+    const int H = (S > 1 && nqb > 1 && nruns > 4 * S) ? ix->f32_helpers : 0;
+    const int S_out = S + H;
 
     if (int rc = ix->Qp.ensure((size_t)nqb * nks * ipx::STAGE_B_BYTES)) return rc;
     if (int rc = ix->cand.ensure((size_t)G * ipx::BQ * cap * sizeof(uint64_t))) return rc;
     if (int rc = ix->err.ensure(256)) return rc;
     if (S > 1) {
-        if (int rc = ix->partD.ensure(nout * S * sizeof(float))) return rc;
-        if (int rc = ix->partI.ensure(nout * S * sizeof(int64_t))) return rc;
+        if (int rc = ix->partD.ensure(nout * S_out * sizeof(float))) return rc;
+        if (int rc = ix->partI.ensure(nout * S_out * sizeof(int64_t))) return rc;
     }
-    // per search: run counters [nqb] (padded to 256 B) then published thresholds [G][256], all zero
-    const size_t ctr_bytes = ((size_t)nqb * sizeof(uint32_t) + 255) / 256 * 256;
+    // per search: run counters [nqb] and helper-slot counters [nqb] (each padded to 256 B), then published
+    // thresholds [G][256], all zero
+    const size_t half_ctr = ((size_t)nqb * sizeof(uint32_t) + 255) / 256 * 256;
+    const size_t ctr_bytes = 2 * half_ctr;
     const size_t pub_bytes = ctr_bytes + (size_t)G * ipx::BQ * sizeof(uint32_t);
     if (int rc = ix->pub.ensure(pub_bytes)) return rc;
     IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
@@ -399,7 +408,16 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
     p.k = k;
     p.cap = cap;
     p.S = S;
+    p.S_out = S > 1 ? S_out : 1;
+    p.helpers = H;
+    p.help_ctr = (uint32_t*)((char*)ix->pub.p + half_ctr);
     p.ntiles = ntiles;
+    if (H > 0) {   // helper slots nobody takes must read as empty lists
+        const int64_t nfill = (int64_t)nout * S_out;
+        hipLaunchKernelGGL(ipx::fill_empty_kernel, dim3((unsigned)((nfill + 255) / 256)), dim3(256), 0, st, (float*)ix->partD.p,
+                           (int64_t*)ix->partI.p, nfill);
+        IPX_HIP(hipGetLastError());
+    }
     const int lds = std::max(2 * ipx::STAGE_BYTES, 4 * cap * 8) + ipx::LDS_STATE_BYTES;
     if (lds > 64 * 1024)
         IPX_HIP(hipFuncSetAttribute((const void*)ipx::scan_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -415,8 +433,8 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
                                         hipFuncAttributeMaxDynamicSharedMemorySize, mlds));
         // partials are [nq][S][k]: shard stride k, query stride S*k; lists arrive sorted
         hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st,
-                           (const float*)ix->partD.p, (const int64_t*)ix->partI.p, S, nq, k, k, P, 1,
-                           (int64_t)k, (int64_t)S * k, dD, dI, (const int*)nullptr);
+                           (const float*)ix->partD.p, (const int64_t*)ix->partI.p, S_out, nq, k, k, P, 1,
+                           (int64_t)k, (int64_t)S_out * k, dD, dI, (const int*)nullptr);
         IPX_HIP(hipGetLastError());
         if (record) {
             IPX_HIP(hipEventRecord(ix->ev[3], st));
@@ -516,6 +534,9 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     p.k = kc;
     p.cap = cap;
     p.S = S;
+    p.S_out = S;
+    p.helpers = 0;
+    p.help_ctr = nullptr;
     p.ntiles = ntiles;
     const int lds = std::max(ring, nsortwaves * cap * 8) + ipx::LDS_STATE_BYTES;
     {
@@ -1054,6 +1075,11 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
             return fail(IPX_ERR_STATE, "set_param: storage can only be chosen while the index is empty and unreserved");
         if (value != 0 && ix->d > 8192) return fail(IPX_ERR_ARG, "set_param: bf16 storage needs d <= 8192");
         ix->storage = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "f32_helpers")) {
+        if (value < 0 || value > 64) return fail(IPX_ERR_ARG, "set_param: f32_helpers outside [0, 64]");
+        ix->f32_helpers = (int)value;
         return 0;
     }
     if (!strcmp(name, "run_tiles")) {

@@ -194,6 +194,9 @@ struct ScanParams {
     int nq, nks, k, cap, S, ntiles;
     int r;               // ceil(k / S): rank each split publishes (S * r >= k)
     int run_tiles;       // R: tiles per run of the dynamic corpus split
+    int S_out;           // lists per query in outD / outI (S, or S + helpers in scan_f32_kernel)
+    int helpers;         // scan_f32_kernel: list slots per query block for workgroups that finished their own block
+    uint32_t* help_ctr;  // [nqb] helper slots handed out (zeroed per search)
 };
 
 // bitonic sort, descending, of P (power of two) 64-bit keys in LDS by one wave
@@ -237,8 +240,8 @@ __device__ __forceinline__ void compact_query(const ScanParams& p, uint64_t* scr
                 __hip_atomic_store(pub_slot, (uint32_t)(scratch[p.r - 1] >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
-        float* oD = p.outD + ((size_t)qglobal * p.S + split) * p.k;
-        int64_t* oI = p.outI + ((size_t)qglobal * p.S + split) * p.k;
+        float* oD = p.outD + ((size_t)qglobal * p.S_out + split) * p.k;
+        int64_t* oI = p.outI + ((size_t)qglobal * p.S_out + split) * p.k;
         for (int i = lane; i < p.k; i += 64) {
             if (i < m) {
                 const uint64_t key = scratch[i];
@@ -413,7 +416,6 @@ scan_f32_kernel(const ScanParams p) {
     const int h = lane >> 5, l31 = lane & 31;
 
     uint64_t t_start = 0;
-    int n_compact = 0;
 #ifdef IPX_STAMPS
     uint64_t st_bar = 0, st_begin = 0, st_epi = 0, st_filter = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_begin) :: "memory");
@@ -421,15 +423,28 @@ scan_f32_kernel(const ScanParams p) {
     if (p.trace) t_start = __builtin_amdgcn_s_memrealtime();
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int qb = logical / p.S, split = logical - qb * p.S;
+    int qb = logical / p.S, split = logical - qb * p.S;
+    bool helper = false;
+    const int fill_limit = p.cap - 2 * BD;      // a set flag is acted on one tile later
+    int tiles_done = 0, n_compact = 0;
 
+  // A workgroup scans for its own query block first; when that block's runs are used up it looks for
+  // the block with the most runs left and joins it as a helper (a fresh, unpublished list in one of
+  // the block's spare output slots, thresholds taken from the block's union bound): the query
+  // blocks' groups of workgroups run at different speeds (a CU's first workgroup wins most MFMA
+  // issue slots, eight CUs hold a single workgroup), and without this the fastest blocks' workgroups
+  // idle for the last 7 % of the launch.
+  for (;;) {
     // thresholds: -FLT_MAX is faiss's heap neutral (scores must be > it to enter);
     // +inf parks the padding queries of the last block.
     cnts[tid] = 0;
     taus[tid] = ((int64_t)qb * BQ + tid < p.nq) ? -FLT_MAX : INFINITY;
     if (tid < 2) flags[tid] = 0;
-    uint32_t* mypub = p.S > 1 ? p.pub + ((size_t)qb * p.S + split) * BQ : nullptr;
-    const int fill_limit = p.cap - 2 * BD;      // a set flag is acted on one tile later
+    uint32_t* mypub = (p.S > 1 && !helper) ? p.pub + ((size_t)qb * p.S + split) * BQ : nullptr;
+    if (helper) {
+        __syncthreads();
+        poll_union_threshold(p, taus, qb, tid);
+    }
 
     uint64_t* myqueues = p.cand + (size_t)blockIdx.x * BQ * p.cap;
     uint64_t* scratch = (uint64_t*)smem + (size_t)wave * p.cap;
@@ -482,6 +497,11 @@ scan_f32_kernel(const ScanParams p) {
     // so no MFMA ever waits on an LDS read, and a stage's HBM->LDS copy has one full stage
     // (4096 MFMA cycles) to land.
     StageCursor c0{split * R, 0, true};
+    if (helper) {                                   // a helper has no pre-assigned run: its first one is claimed too
+        claim_next_run();
+        c0 = StageCursor{nxt >= 0 ? nxt : 0, 0, nxt >= 0};
+        adv_end = c0.t + R < p.ntiles ? c0.t + R : p.ntiles;
+    }
     claim_next_run();
     StageCursor c1 = advance(c0);
     StageCursor c2 = advance(c1);
@@ -495,7 +515,7 @@ scan_f32_kernel(const ScanParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) b0[j] = *(const f32x4*)(smem + b_off + j * 2048 + pc0);
 
-    int g = 0, tiles_done = 0;
+    int g = 0;
     while (c0.ok) {
         const int t = c0.t;
         if (t == enter_t) claim_next_run();
@@ -660,6 +680,35 @@ scan_f32_kernel(const ScanParams p) {
         if (qglobal < p.nq)
             compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, true, qglobal, split, nullptr);
     }
+    // ---- anything left to help with? thread 0 picks the query block with the most runs left ----
+    if (p.helpers <= 0) break;
+    __syncthreads();
+    if (tid == 0) {
+        const int nruns = (p.ntiles + R - 1) / R, nqb = (int)(gridDim.x / p.S);
+        int pick = -1, most = 3;                    // joining costs a list of its own: not for the last few runs
+        for (int b = 0; b < nqb; ++b) {
+            const int left = nruns - p.S - (int)__hip_atomic_load(p.run_ctr + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (left > most && __hip_atomic_load(p.help_ctr + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)p.helpers) {
+                most = left;
+                pick = b;
+            }
+        }
+        int slot_out = -1;
+        if (pick >= 0) {
+            const uint32_t hslot = atomicAdd(p.help_ctr + pick, 1u);
+            if (hslot < (uint32_t)p.helpers) slot_out = p.S + (int)hslot;
+        }
+        runslot[0] = slot_out >= 0 ? pick : -1;
+        flags[0] = slot_out;
+    }
+    __syncthreads();
+    const int next_qb = runslot[0], next_slot = flags[0];
+    __syncthreads();
+    if (next_qb < 0) break;
+    qb = next_qb;
+    split = next_slot;
+    helper = true;
+  }
 #ifdef IPX_STAMPS
     if (p.trace && lane == 0) {   // diagnostic build: per-wave cycle sums
         uint64_t s_end;

@@ -437,3 +437,21 @@ def test_randomised_merge_and_entry_point_cases(R):
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_merge.py"), "100", "5"],
                          capture_output=True, text=True, timeout=250)
     assert out.returncode == 0 and "all 100 cases ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_helper_workgroups_join_other_query_blocks(R):
+    """scan_f32_kernel: workgroups whose query block has no runs left join the block with the most runs left
+    (a list of their own in a spare output slot). Few splits and several query blocks make most workgroups
+    helpers at some point; results must not depend on it."""
+    X, Q = gaussian(61, (300000, 24)), gaussian(62, (1100, 24))       # 5 query blocks, 2344 corpus tiles
+    ix = R.FlatIPIndex(24)
+    ix.add(X)
+    ix.set_param("run_tiles", 4)
+    S = O.scores_mfma_order(Q, X)
+    for k in (10, 300):
+        rD, rI = O.topk_total_order(S, k)
+        for max_splits, helpers in ((3, 8), (3, 0), (20, 2), (0, 8)):
+            ix.set_param("max_splits", max_splits)
+            ix.set_param("f32_helpers", helpers)
+            D, I = ix.search(Q, k)
+            assert np.array_equal(I, rI) and np.array_equal(D, rD), (k, max_splits, helpers)
