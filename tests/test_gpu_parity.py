@@ -443,8 +443,8 @@ def test_helper_workgroups_join_other_query_blocks(R):
     """scan_f32_kernel: workgroups whose query block has no runs left join the block with the most runs left
     (a list of their own in a spare output slot). Few splits and several query blocks make most workgroups
     helpers at some point; results must not depend on it."""
-    X, Q = gaussian(61, (300000, 24)), gaussian(62, (1100, 24))       # 5 query blocks, 2344 corpus tiles
-    ix = R.FlatIPIndex(24)
+    X, Q = gaussian(61, (160000, 16)), gaussian(62, (700, 16))        # 3 query blocks, 1250 corpus tiles
+    ix = R.FlatIPIndex(16)
     ix.add(X)
     ix.set_param("run_tiles", 4)
     S = O.scores_mfma_order(Q, X)
