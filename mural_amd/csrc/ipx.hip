@@ -358,11 +358,11 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
     const int R = ix->run_tiles > 0 ? ix->run_tiles : std::max(4, std::min(64, ntiles / (S * 256)));
     const int nruns = (ntiles + R - 1) / R;
     S = std::min(S, nruns);
-    const int G = nqb * S;
     const int cap = std::max(512, next_pow2(2 * k));
     // spare list slots per query block for workgroups that finish their own block early (scan_f32_kernel)
     const int H = (S > 1 && nqb > 1 && nruns > 4 * S) ? ix->f32_helpers : 0;
     const int S_out = S + H;
+    const int G = nqb * S;
 
     if (int rc = ix->Qp.ensure((size_t)nqb * nks * ipx::STAGE_B_BYTES)) return rc;
     if (int rc = ix->cand.ensure((size_t)G * ipx::BQ * cap * sizeof(uint64_t))) return rc;

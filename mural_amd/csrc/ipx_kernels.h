@@ -427,6 +427,41 @@ scan_f32_kernel(const ScanParams p) {
     bool helper = false;
     const int fill_limit = p.cap - 2 * BD;      // a set flag is acted on one tile later
     int tiles_done = 0, n_compact = 0;
+    const int nqb = (p.nq + BQ - 1) / BQ;
+    // Thread 0 picks the query block with the most runs left (starting the search at a block of this
+    // workgroup's own, so simultaneous pickers spread out) and takes one of its spare output slots.
+    auto pick_block = [&]() -> bool {
+        __syncthreads();
+        if (tid == 0) {
+            const int Rr = p.run_tiles, nruns = (p.ntiles + Rr - 1) / Rr;
+            int pick = -1, most = 3;                // joining costs a list of its own: not for the last few runs
+            for (int i = 0; i < nqb; ++i) {
+                const int b = (int)((blockIdx.x + i) % nqb);
+                const int left = nruns - p.S - (int)__hip_atomic_load(p.run_ctr + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (left > most && __hip_atomic_load(p.help_ctr + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)p.helpers) {
+                    most = left;
+                    pick = b;
+                }
+            }
+            int slot_out = -1;
+            if (pick >= 0) {
+                const uint32_t hslot = atomicAdd(p.help_ctr + pick, 1u);
+                if (hslot < (uint32_t)p.helpers) slot_out = p.S + (int)hslot;
+            }
+            runslot[0] = slot_out >= 0 ? pick : -1;
+            flags[0] = slot_out;
+        }
+        __syncthreads();
+        const int next_qb = runslot[0], next_slot = flags[0];
+        __syncthreads();
+        if (next_qb < 0) return false;
+        qb = next_qb;
+        split = next_slot;
+        helper = true;
+        return true;
+    };
+    // (Filling the eight CU slots the grid leaves empty with workgroups that help from the start was
+    // measured too: no gain — the lone workgroups of those CUs already run that much faster.)
 
   // A workgroup scans for its own query block first; when that block's runs are used up it looks for
   // the block with the most runs left and joins it as a helper (a fresh, unpublished list in one of
@@ -680,34 +715,8 @@ scan_f32_kernel(const ScanParams p) {
         if (qglobal < p.nq)
             compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, true, qglobal, split, nullptr);
     }
-    // ---- anything left to help with? thread 0 picks the query block with the most runs left ----
-    if (p.helpers <= 0) break;
-    __syncthreads();
-    if (tid == 0) {
-        const int nruns = (p.ntiles + R - 1) / R, nqb = (int)(gridDim.x / p.S);
-        int pick = -1, most = 3;                    // joining costs a list of its own: not for the last few runs
-        for (int b = 0; b < nqb; ++b) {
-            const int left = nruns - p.S - (int)__hip_atomic_load(p.run_ctr + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (left > most && __hip_atomic_load(p.help_ctr + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)p.helpers) {
-                most = left;
-                pick = b;
-            }
-        }
-        int slot_out = -1;
-        if (pick >= 0) {
-            const uint32_t hslot = atomicAdd(p.help_ctr + pick, 1u);
-            if (hslot < (uint32_t)p.helpers) slot_out = p.S + (int)hslot;
-        }
-        runslot[0] = slot_out >= 0 ? pick : -1;
-        flags[0] = slot_out;
-    }
-    __syncthreads();
-    const int next_qb = runslot[0], next_slot = flags[0];
-    __syncthreads();
-    if (next_qb < 0) break;
-    qb = next_qb;
-    split = next_slot;
-    helper = true;
+    // ---- anything left to help with? ----
+    if (p.helpers <= 0 || !pick_block()) break;
   }
 #ifdef IPX_STAMPS
     if (p.trace && lane == 0) {   // diagnostic build: per-wave cycle sums
