@@ -47,12 +47,12 @@ def _lookup_strings(p_lookup, all_indices):
     hit[flat] = True
     uniq = np.flatnonzero(hit)
     got = operator.itemgetter(*uniq.tolist())(p_lookup) if uniq.size > 1 else (p_lookup[int(uniq[0])],)
-    table = np.array(got) if all(type(x) is str for x in got) else np.array([str(x) for x in got])
+    table = np.array(got) if set(map(type, got)) == {str} else np.array([str(x) for x in got])
     slot = np.cumsum(hit, dtype=np.int64) - 1
     out = table[slot[flat]].reshape(all_indices.shape)
-    # np.array(list of str lists) sizes the dtype to the longest string present
-    width = max(int(np.char.str_len(out).max()), 1)
-    return out.astype(f"<U{width}")
+    # np.array(list of str lists) sizes the dtype to the longest string present: every table entry is
+    # present in `out`, so the table's own width is that width (at least 1, as numpy gives '' -> '<U1')
+    return out if out.dtype.itemsize >= 4 else out.astype("<U1")
 
 
 def search_queries(retriever, q_reps, p_lookup, args):
