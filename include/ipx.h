@@ -140,7 +140,11 @@ int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in
  *   "no_small_batch" : 1 = always use the 256-query tiles (A/B measurements, tests).
  *   "bf16_waves" : large-batch bf16 scan with 8 or 16 waves per workgroup (0 = automatic: 16 with
  *                  one query part, 8 with two; results do not depend on it).
- *   "bf16_shape16" : 1 = the 16-wave bf16 scan uses v_mfma_f32_16x16x32_bf16 (measurement aid).
+ *   "bf16_shape16" : the 16-wave bf16 scan uses v_mfma_f32_16x16x32_bf16 (1, default: measured 2-4 % faster
+ *                  on the 8.8M x 768 workload) or v_mfma_f32_32x32x16_bf16 (0).
+ *   "bf16_variant", "bf16_map", "bf16_pp" : measurement aids of the large-batch bf16 scan (issue order behind the
+ *                  stage barrier + non-temporal corpus pieces; workgroup -> (query block, split) mapping;
+ *                  1 / 2 = ping-pong kernel, 3 / 4 = direct-corpus-operand kernel, see csrc/ipx_bf16_*_kernels.h).
  *   "run_tiles"  : fp32 large-tile scan: corpus tiles per run of the dynamic split (0 = automatic).
  *   "trace"      : 1 = every scan workgroup records {start, end (100 MHz ticks), HW_ID,
  *                  compactions}; read back with ipx_read_trace (profiling aid). */

@@ -7,6 +7,8 @@
 #include "ipx_bf16_kernels.h"
 #include "ipx_f32_small_kernels.h"
 #include "ipx_bf16_w16_kernels.h"
+#include "ipx_bf16_pp_kernels.h"
+#include "ipx_bf16_dx_kernels.h"
 #include "../../include/ipx.h"
 
 #include <algorithm>
@@ -65,6 +67,7 @@ int next_pow2(int x) {
 
 struct ipx_index {
     int d = 0, nks = 0, device = 0;
+    int num_cus = 0;         // multiProcessorCount of `device`, read once at create
     int64_t ntotal = 0;
     int64_t cap_tiles = 0;   // tiles of 128 rows the corpus buffer holds
     int64_t id_base = 0;
@@ -92,9 +95,12 @@ struct ipx_index {
     int force_kc = 0;        // 0 = automatic candidate count
     int query_parts = 0;     // 0 = automatic; 1 / 2 bf16 parts per query in the bf16 scan
     int small_f32_limit = 192;     // fp32 scans of up to this many queries take scan_f32_small_kernel
-    bool bf16_shape16 = false;     // 16-wave scan, one query part: v_mfma_f32_16x16x32_bf16 instead of 32x32x16
+    bool bf16_shape16 = true;      // 16-wave scan, one query part: v_mfma_f32_16x16x32_bf16 (measured 2-4 % faster) / 32x32x16
     int f32_helpers = 8;           // fp32 large-tile scan: helper list slots per query block (0 = no work stealing)
     int run_tiles = 0;             // fp32 large-tile scan: corpus tiles per run of the dynamic split (0 = automatic)
+    int bf16_pp = 0;               // large-batch bf16 scan, one query part: 1 / 2 = ping-pong kernel (2: with s_setprio)
+    int bf16_map = 0;              // large-batch bf16 scan: ScanParams::map
+    int bf16_variant = 0;          // 16-wave bf16 scan, one query part: issue order behind the barrier (0..3) + 4 * non-temporal corpus pieces
     int bf16_waves = 0;            // large-batch bf16 scan: 8 (scan_bf16_kernel<4>) or 16 waves (scan_bf16_w16_kernel); 0 = automatic
     bool no_small_batch = false;   // diagnostic: always use the 256-query bf16 scan variant
     bool force_f32_scan = false;   // storage 1: use the fp32 scan although a bf16 copy exists
@@ -161,13 +167,13 @@ int grow_corpus_h(ipx_index* ix, int64_t need_tiles, hipStream_t st) {
 }
 
 int launch_pack_bf16(const void* src, int dtype, int64_t n, int64_t n_pad, int d, uint16_t* dst, int64_t row0,
-                     int rows_per_tile, int nks_h, int parts, hipStream_t st) {
+                     int rows_per_tile, int nks_h, int parts, hipStream_t st, int swz = 0) {
     const int64_t total = n_pad * nks_h * 4;
     if (total == 0) return 0;
     const int64_t blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return fail(IPX_ERR_ARG, "pack: too many rows in one call");
     hipLaunchKernelGGL(ipx::pack_rows_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dtype, n, n_pad, d,
-                       dst, row0, rows_per_tile, nks_h, parts);
+                       dst, row0, rows_per_tile, nks_h, parts, swz);
     IPX_HIP(hipGetLastError());
     return 0;
 }
@@ -230,9 +236,7 @@ int scan_f32_small_path(ipx_index* ix, const float* dq, const float* dw, int A, 
     const int bq = 32 * qt;
     const int nqb = (int)((nq + bq - 1) / bq);
     const int ntiles = (int)((N + ipx::BD - 1) / ipx::BD);
-    hipDeviceProp_t prop;
-    IPX_HIP(hipGetDeviceProperties(&prop, ix->device));
-    const int resident = 2 * prop.multiProcessorCount;      // two 512-thread workgroups per CU
+    const int resident = 2 * ix->num_cus;                   // two 512-thread workgroups per CU
     const int npairs = (ntiles + 1) / 2;                    // the kernel steps through pairs of corpus tiles
     int S = std::max(1, resident / nqb);
     if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
@@ -348,9 +352,7 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
     const int nqb = (int)((nq + ipx::BQ - 1) / ipx::BQ);
     const int ntiles = (int)((N + ipx::BD - 1) / ipx::BD);
     // geometry: (up to) all workgroups resident at once, 2 per CU; S of them share a query block.
-    hipDeviceProp_t prop;
-    IPX_HIP(hipGetDeviceProperties(&prop, ix->device));
-    const int resident = 2 * prop.multiProcessorCount;
+    const int resident = 2 * ix->num_cus;
     // A query block's S workgroups take runs of R corpus tiles from a shared counter.
     int S = std::max(1, resident / nqb);
     if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
@@ -474,9 +476,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     const int stage_b = bq * 64 * qparts;
     const int nqb = (int)((nq + bq - 1) / bq);
     const int ntiles = (int)((N + ipx::HBD - 1) / ipx::HBD);
-    hipDeviceProp_t prop;
-    IPX_HIP(hipGetDeviceProperties(&prop, ix->device));
-    const int resident = prop.multiProcessorCount;          // one 512-thread workgroup per CU
+    const int resident = ix->num_cus;                       // one 512-thread workgroup per CU
     int S = std::max(1, resident / nqb);
     if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
     int R = 4;                                               // tiles per run: a power of two in [4, 64]
@@ -500,14 +500,19 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
         if (int rc = ix->partD.ensure(ncand * S * sizeof(float))) return rc;
         if (int rc = ix->partI.ensure(ncand * S * sizeof(int64_t))) return rc;
     }
-    const size_t ctr_bytes = ((size_t)nqb * sizeof(uint32_t) + 255) / 256 * 256;
+    // per search, zeroed: run counters [nqb] (unused by these kernels), meeting counters [S] (scan_bf16_dx_kernel)
+    const size_t ctr_bytes = ((size_t)(nqb + S) * sizeof(uint32_t) + 255) / 256 * 256;
     // published bounds: up to 4 values per split and query on the small-batch short-list path
     const size_t pub_bytes = ctr_bytes + (size_t)G * bq * (small ? 4 : 1) * sizeof(uint32_t);
     if (int rc = ix->pub.ensure(pub_bytes)) return rc;
     IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
 
+    // large batches, one query part: the ping-pong kernels (both operands in LDS: any even number of K-stages;
+    // corpus operand straight into registers: a multiple of 6)
+    const bool pp = !small && qparts == 1 && (ix->bf16_pp == 1 || ix->bf16_pp == 2) && (nks & 1) == 0;
+    const bool dx = !small && qparts == 1 && (ix->bf16_pp == 3 || ix->bf16_pp == 4) && nks % 6 == 0;
     if (timing) IPX_HIP(hipEventRecord(ix->ev[0], st));
-    if (int rc = launch_pack_bf16(qf, IPX_F32, nq, (int64_t)nqb * bq, d, (uint16_t*)ix->Qp.p, 0, bq, nks, qparts, st)) return rc;
+    if (int rc = launch_pack_bf16(qf, IPX_F32, nq, (int64_t)nqb * bq, d, (uint16_t*)ix->Qp.p, 0, bq, nks, qparts, st, dx ? 1 : 0)) return rc;
     if (timing) IPX_HIP(hipEventRecord(ix->ev[1], st));
 
     ipx::ScanParams p;
@@ -538,6 +543,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     p.helpers = 0;
     p.help_ctr = nullptr;
     p.ntiles = ntiles;
+    p.map = small ? 0 : ix->bf16_map;
     const int lds = std::max(ring, nsortwaves * cap * 8) + ipx::LDS_STATE_BYTES;
     {
         // one query part: the 16-wave variant is 9 % faster (8.8M x 768, 6980 queries: 93 vs 102 ms);
@@ -548,8 +554,22 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
             : w16 ? (qparts == 2 ? ipx::scan_bf16_w16_kernel<2, false>
                                  : (ix->bf16_shape16 ? ipx::scan_bf16_w16_kernel<1, true> : ipx::scan_bf16_w16_kernel<1, false>))
                   : (qparts == 2 ? ipx::scan_bf16_kernel<4, 2> : ipx::scan_bf16_kernel<4, 1>);
+        if (w16 && qparts == 1 && !ix->bf16_shape16) {
+            switch (ix->bf16_variant) {
+                case 1: kern = ipx::scan_bf16_w16_kernel<1, false, 1, false>; break;
+                case 2: kern = ipx::scan_bf16_w16_kernel<1, false, 2, false>; break;
+                case 3: kern = ipx::scan_bf16_w16_kernel<1, false, 3, false>; break;
+                case 4: kern = ipx::scan_bf16_w16_kernel<1, false, 0, true>; break;
+                case 5: kern = ipx::scan_bf16_w16_kernel<1, false, 1, true>; break;
+                case 6: kern = ipx::scan_bf16_w16_kernel<1, false, 2, true>; break;
+                case 7: kern = ipx::scan_bf16_w16_kernel<1, false, 3, true>; break;
+                default: break;
+            }
+        }
+        if (pp) kern = ix->bf16_pp == 2 ? ipx::scan_bf16_pp_kernel<true> : ipx::scan_bf16_pp_kernel<false>;
+        if (dx) kern = ix->bf16_pp == 4 ? ipx::scan_bf16_dx_kernel<true> : ipx::scan_bf16_dx_kernel<false>;
         IPX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(kern, dim3(G), dim3(w16 ? 1024 : ipx::HTHREADS), lds, st, p, nsortwaves);
+        hipLaunchKernelGGL(kern, dim3(G), dim3((pp || dx) ? 512 : w16 ? 1024 : ipx::HTHREADS), lds, st, p, nsortwaves);
     }
     IPX_HIP(hipGetLastError());
     if (timing) IPX_HIP(hipEventRecord(ix->ev[2], st));
@@ -819,6 +839,13 @@ int ipx_create(int d, int device, ipx_index** out) {
     ix->nks = (d + ipx::BK - 1) / ipx::BK;
     ix->nks_h = (d + ipx::HBK - 1) / ipx::HBK;
     ix->device = device;
+    int cus = 0;
+    hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (e != hipSuccess || cus <= 0) {
+        delete ix;
+        return fail(IPX_ERR_HIP, std::string("create: multiprocessor count: ") + hipGetErrorString(e));
+    }
+    ix->num_cus = cus;
     *out = ix;
     return 0;
 }
@@ -1089,6 +1116,20 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
     }
     if (!strcmp(name, "bf16_shape16")) {
         ix->bf16_shape16 = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "bf16_pp")) {
+        if (value < 0 || value > 4) return fail(IPX_ERR_ARG, "set_param: bf16_pp outside [0, 4]");
+        ix->bf16_pp = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "bf16_map")) {
+        ix->bf16_map = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "bf16_variant")) {
+        if (value < 0 || value > 7) return fail(IPX_ERR_ARG, "set_param: bf16_variant outside [0, 7]");
+        ix->bf16_variant = (int)value;
         return 0;
     }
     if (!strcmp(name, "bf16_waves")) {

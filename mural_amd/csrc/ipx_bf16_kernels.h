@@ -97,12 +97,17 @@ mural_pool_kernel(const float* __restrict__ h, const float* __restrict__ W, cons
     }
 }
 
+// Swizzle of the query blocks that scan_bf16_dx_kernel reads with 16-row operand reads (ipx_bf16_dx_kernels.h):
+// chunk c of row r sits at slot c ^ sigma((r >> 2) & 3), sigma = 0, 2, 3, 1.
+__device__ __forceinline__ int dx_sigma(int q) { return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1); }
+
 // row-major [n, d] (f32 / f16 / bf16) -> tiled, padded, swizzled bf16 (round to nearest even).
 // One thread per (row, 16-byte chunk of 8 bf16). parts == 2 (queries only) also writes the
 // residual lo = bf16(x - hi) as a second block behind each stage: x ~ hi + lo to 16 bits.
+// swz == 1 (queries only): the dx_sigma swizzle instead of the corpus one.
 __global__ void __launch_bounds__(256)
 pack_rows_bf16_kernel(const void* __restrict__ src, int dtype, int64_t n, int64_t n_pad, int d,
-                      uint16_t* __restrict__ dst, int64_t row0, int rows_per_tile, int nks, int parts) {
+                      uint16_t* __restrict__ dst, int64_t row0, int rows_per_tile, int nks, int parts, int swz) {
     const int nchunks = nks * 4;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t r = gid / nchunks;
@@ -127,7 +132,7 @@ pack_rows_bf16_kernel(const void* __restrict__ src, int dtype, int64_t n, int64_
     const int64_t R = row0 + r;
     const int64_t tile = R / rows_per_tile;
     const int rr = (int)(R - tile * rows_per_tile);
-    const int ks = c >> 2, pc = (c & 3) ^ ((rr >> 2) & 3);
+    const int ks = c >> 2, pc = (c & 3) ^ (swz ? dx_sigma((rr >> 2) & 3) : ((rr >> 2) & 3));
     uint16_t* o = dst + (((tile * nks + ks) * parts) * rows_per_tile + rr) * 32 + pc * 8;
     uint4 out;
     out.x = v[0] | ((uint32_t)v[1] << 16);
@@ -336,7 +341,9 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
     const int h = lane >> 5, l31 = lane & 31;
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int qb = logical / p.S, split = logical - qb * p.S;
+    const int nqb_ = (int)gridDim.x / p.S;
+    const int qb = p.map ? logical % nqb_ : logical / p.S;
+    const int split = p.map ? logical / nqb_ : logical - qb * p.S;
 
     if (tid < BQ_) {
         cnts[tid] = 0;

@@ -19,7 +19,9 @@ template <int QP> struct WCfg {
     static constexpr int RING = NBUF * STAGE;
 };
 
-template <int QP>
+#define IPX_GLDS_NT(g_, l_) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g_), \
+                                                              (__attribute__((address_space(3))) void*)(l_), 16, 0, 2)
+template <int QP, bool NT = false>
 struct WPieces {
     const char* ga;
     const char* gb;
@@ -29,11 +31,14 @@ struct WPieces {
         gb = (const char*)p.Qp + ((size_t)qb * p.nks + ks) * (WCfg<QP>::PART_B * QP) + wave * 1024 + lane * 16;
         la = buf + wave * 1024;
     }
-    __device__ __forceinline__ void issue_all() const {
-        IPX_GLDS(ga, la);
+    __device__ __forceinline__ void issue_a() const {
+        if constexpr (NT) IPX_GLDS_NT(ga, la); else IPX_GLDS(ga, la);
+    }
+    __device__ __forceinline__ void issue_b() const {
         IPX_GLDS(gb, la + HSTAGE_A);
         if constexpr (QP == 2) IPX_GLDS(gb + WCfg<QP>::PART_B, la + HSTAGE_A + WCfg<QP>::PART_B);
     }
+    __device__ __forceinline__ void issue_all() const { issue_a(); issue_b(); }
 };
 
 __device__ __forceinline__ void w16_wait4(f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1) {
@@ -48,10 +53,14 @@ __device__ __forceinline__ void w16_wait2(f32x4& b0, f32x4& b1) {
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A1_), as_bf16x8(B0_), acc[1][0], 0, 0, 0);          \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A1_), as_bf16x8(B1_), acc[1][1], 0, 0, 0)
 
-template <int QP, bool S16>
+// ORD: issue order behind the per-stage barrier: 0 = copy pieces, then the four MFMAs; 1 = MFMAs, then pieces;
+//      2 = two MFMAs, corpus piece, two MFMAs, query piece(s); 3 = as 1 with s_setprio 1 around the MFMAs.
+// NT : corpus pieces carry the non-temporal hint (they do not displace the query blocks from L2).
+template <int QP, bool S16, int ORD = 0, bool NT = false>
 __global__ void __launch_bounds__(1024)
 scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
     static_assert(!S16 || QP == 1, "the 16x16x32 variant exists for one query part");
+    static_assert(!S16 || ORD == 0, "issue-order variants exist for the 32x32x16 form");
     using C = WCfg<QP>;
     constexpr int BQ_ = 256, NBUF = C::NBUF, STAGE = C::STAGE, LOADS = C::LOADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -67,7 +76,9 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
     const int h = lane >> 5, l31 = lane & 31;
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int qb = logical / p.S, split = logical - qb * p.S;
+    const int nqb_ = (int)gridDim.x / p.S;
+    const int qb = p.map ? logical % nqb_ : logical / p.S;
+    const int split = p.map ? logical / nqb_ : logical - qb * p.S;
 
     if (tid < BQ_) {
         cnts[tid] = 0;
@@ -109,7 +120,7 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
     Walker wi = w0;
 #pragma unroll 1
     for (int i = 0; i < NBUF; ++i) {
-        WPieces<QP>(p, smem + i * STAGE, wi.t, qb, wi.ks, wave, lane).issue_all();
+        WPieces<QP, NT>(p, smem + i * STAGE, wi.t, qb, wi.ks, wave, lane).issue_all();
         advance(wi);
     }
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 1)) : "memory");
@@ -155,7 +166,7 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
                 if constexpr (QP == 2) {
                     IPX_DS_READ_B128(c0, buf + b_off + C::PART_B + pc1, 0); IPX_DS_READ_B128(c1, buf + b_off + C::PART_B + pc1, 2048);
                 }
-                const WPieces<QP> sp(p, smem + slot * STAGE, wi.t, qb, wi.ks, wave, lane);
+                const WPieces<QP, NT> sp(p, smem + slot * STAGE, wi.t, qb, wi.ks, wave, lane);
                 if constexpr (QP == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1) :: "memory");
                 else w16_wait4(a0, a1, b0, b1);
                 // this wave's last reads of the slot are in registers; its pieces of the next stage have landed
@@ -163,9 +174,29 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                sp.issue_all();
-                IPX_W16_MFMA4(a0, a1, b0, b1);
-                if constexpr (QP == 2) { IPX_W16_MFMA4(a0, a1, c0, c1); }
+                if constexpr (ORD == 0) {
+                    sp.issue_all();
+                    IPX_W16_MFMA4(a0, a1, b0, b1);
+                    if constexpr (QP == 2) { IPX_W16_MFMA4(a0, a1, c0, c1); }
+                } else if constexpr (ORD == 2) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(b0), acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(b1), acc[0][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    sp.issue_a();
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(b0), acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(b1), acc[1][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    sp.issue_b();
+                    if constexpr (QP == 2) { IPX_W16_MFMA4(a0, a1, c0, c1); }
+                } else {
+                    if constexpr (ORD == 3) __builtin_amdgcn_s_setprio(1);
+                    IPX_W16_MFMA4(a0, a1, b0, b1);
+                    if constexpr (QP == 2) { IPX_W16_MFMA4(a0, a1, c0, c1); }
+                    if constexpr (ORD == 3) __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    sp.issue_all();
+                }
                 asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
                 advance(wi);
                 advance(w0);
@@ -237,7 +268,7 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
                 IPX_W16_ROW(1, b1);
                 __builtin_amdgcn_sched_barrier(0);
                 IPX_DS_READ_B128(b0, buf + b16, 2048); IPX_DS_READ_B128(b1, buf + b16, 3072);
-                const WPieces<QP> sp(p, smem + slot * STAGE, wi.t, qb, wi.ks, wave, lane);
+                const WPieces<QP, NT> sp(p, smem + slot * STAGE, wi.t, qb, wi.ks, wave, lane);
                 w16_wait2(b0, b1);
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
                 __builtin_amdgcn_s_barrier();
@@ -300,7 +331,7 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
 #pragma unroll 1
             for (int i = 0; i < NBUF; ++i) {
                 const int sl = slot + i < NBUF ? slot + i : slot + i - NBUF;
-                WPieces<QP>(p, smem + sl * STAGE, wr.t, qb, wr.ks, wave, lane).issue_all();
+                WPieces<QP, NT>(p, smem + sl * STAGE, wr.t, qb, wr.ks, wave, lane).issue_all();
                 advance(wr);
             }
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 1)) : "memory");

@@ -197,6 +197,9 @@ struct ScanParams {
     int S_out;           // lists per query in outD / outI (S, or S + helpers in scan_f32_kernel)
     int helpers;         // scan_f32_kernel: list slots per query block for workgroups that finished their own block
     uint32_t* help_ctr;  // [nqb] helper slots handed out (zeroed per search)
+    int map = 0;         // bf16 large-batch scans: 0 = logical ids query-block-major (an XCD holds few query blocks x all
+                         // splits), 1 = split-major (an XCD holds one or two corpus splits x all query blocks: the
+                         // workgroups behind one L2 / the Infinity Cache stream the same corpus tiles)
 };
 
 // bitonic sort, descending, of P (power of two) 64-bit keys in LDS by one wave

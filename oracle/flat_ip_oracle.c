@@ -24,6 +24,18 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* threads the parallel loops below use (1 when built without OpenMP) */
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 /* ---- binary heap over (value, id) pairs, 1-based sifting as in faiss utils/Heap.h ----
  * keep_largest != 0 : CMin ordering (root = smallest kept value; used for inner product)
@@ -63,6 +75,9 @@ void orc_heap_init(int keep_largest, int64_t nq, int64_t k, float* D, int64_t* I
  * a value enters only if it is strictly better than the root. */
 void orc_heap_addn(int keep_largest, int64_t nq, int64_t k, float* D, int64_t* I,
                    const float* vals, const int64_t* ids, int64_t nj, int64_t ld, int64_t j0) {
+    /* faiss runs this loop "#pragma omp parallel for" over the queries (HeapResultHandler::add_results);
+     * each query's heap is private, so the result does not depend on the thread count */
+#pragma omp parallel for schedule(static) if (nq > 1)
     for (int64_t q = 0; q < nq; ++q) {
         float* hd = D + q * k;
         int64_t* hi = I + q * k;
@@ -77,6 +92,7 @@ void orc_heap_addn(int keep_largest, int64_t nq, int64_t k, float* D, int64_t* I
 
 /* heap_reorder: pop everything, best first; unused slots go last as (neutral, -1) */
 void orc_heap_reorder(int keep_largest, int64_t nq, int64_t k, float* D, int64_t* I) {
+#pragma omp parallel for schedule(static) if (nq > 1)
     for (int64_t q = 0; q < nq; ++q) {
         float* hd = D + q * k;
         int64_t* hi = I + q * k;

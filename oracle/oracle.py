@@ -51,8 +51,14 @@ def _c():
         L.orc_heap_addn.argtypes = [i32, i64, i64, vp, vp, vp, vp, i64, i64, i64]
         L.orc_heap_reorder.argtypes = [i32, i64, i64, vp, vp]
         L.orc_scores_mfma_order.argtypes = [vp, vp, i64, i64, i64, vp]
+        L.orc_num_threads.restype = i32
         _lib = L
     return _lib
+
+
+def num_threads():
+    """OpenMP threads the heap stages run on (the sgemm's threads are OpenBLAS's own)."""
+    return int(_c().orc_num_threads())
 
 
 class FlatIPOracle:

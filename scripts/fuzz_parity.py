@@ -21,7 +21,7 @@ rng = np.random.default_rng(seed)
 t0 = time.time()
 for c in range(cases):
     n = int(rng.choice([1, 2, 127, 128, 129, 255, 256, 257, 511, 513, int(rng.integers(1, 3000)), int(rng.integers(3000, 60000))]))
-    d = int(rng.choice([1, 7, 8, 16, 17, 31, 32, 33, 48, 64, 100, 128, int(rng.integers(1, 300))]))
+    d = int(rng.choice([1, 7, 8, 16, 17, 31, 32, 33, 48, 64, 100, 128, 192, int(rng.integers(1, 300))]))
     nq = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 192, 193, 256, 257, int(rng.integers(1, 400))]))
     if BIGD:           # long rows: many K-stages per tile
         n = int(rng.integers(1, 3000)); d = int(rng.choice([768, 1000, 1024, 4096, 8192])); nq = int(rng.choice([1, 33, 70, 260]))
@@ -76,10 +76,18 @@ for c in range(cases):
     if storage != "f32":
         variants += [("bf16 large", {"no_small_batch": 1}), ("bf16 parts 1", {"query_parts": 1}), ("bf16 parts 2", {"query_parts": 2}),
                      ("bf16 8 waves", {"no_small_batch": 1, "bf16_waves": 8, "query_parts": int(rng.choice([1, 2]))}),
-                     ("bf16 16 waves", {"no_small_batch": 1, "bf16_waves": 16, "query_parts": int(rng.choice([1, 2]))})]
+                     ("bf16 16 waves", {"no_small_batch": 1, "bf16_waves": 16, "query_parts": int(rng.choice([1, 2])),
+                                        "bf16_shape16": int(rng.choice([0, 1])), "bf16_variant": int(rng.integers(0, 8)),
+                                        "bf16_map": int(rng.choice([0, 1]))}),
+                     # ping-pong kernels (both operands in LDS / corpus operand straight into registers); shapes they
+                     # do not serve (odd K-stage counts, two query parts) fall back to the 16-wave kernel
+                     ("bf16 ping-pong", {"no_small_batch": 1, "query_parts": 1, "bf16_pp": int(rng.choice([1, 2])),
+                                         "bf16_map": int(rng.choice([0, 1]))}),
+                     ("bf16 direct corpus", {"no_small_batch": 1, "query_parts": 1, "bf16_pp": int(rng.choice([3, 4]))})]
     for name, params in variants:
-        for key in ("f32_scan", "no_small_batch", "query_parts", "bf16_waves"):
+        for key in ("f32_scan", "no_small_batch", "query_parts", "bf16_waves", "bf16_variant", "bf16_map", "bf16_pp"):
             ix.set_param(key, 0)
+        ix.set_param("bf16_shape16", 1)
         ix.set_param("small_f32_limit", 192)
         for key, val in params.items():
             ix.set_param(key, val)
