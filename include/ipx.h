@@ -84,6 +84,22 @@ int ipx_add(ipx_index* idx, const void* rows, int64_t n, int dtype, int on_devic
 int ipx_search(ipx_index* idx, const float* q, int64_t nq, int k,
                float* out_D, int64_t* out_I, int on_device, void* stream);
 
+/* No counterpart in the reference: ipx_search for callers that cannot allocate device memory while they run (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc). Same results as ipx_search, bit
+ * for bit. Device pointers only (q, out_D, out_I on the index's GPU), stream-ordered, returns without
+ * synchronising (ipx_check reports a flagged invariant violation); the index must keep fp32 rows (storage 0 or 1).
+ * Calls no hipMalloc / hipFree and creates no events: every intermediate buffer lives in a static device array of
+ * IPX_NOALLOC_SCRATCH_BYTES that each GPU the library runs on holds until the process ends. Limits: nq <=
+ * IPX_NOALLOC_MAX_QUERIES, k <= IPX_MAX_K, and (nq, k, d) whose buffers fit the array with at least one corpus
+ * split (the corpus is cut into as many splits as fit: fewer than ipx_search uses, so it is slower on large
+ * indexes); anything beyond is IPX_ERR_ARG with the sizes in the message. All calls on one GPU share that GPU's
+ * array: two calls that overlap in time on one GPU (different streams or threads, any indexes) race; calls on one
+ * stream are ordered and safe. */
+#define IPX_NOALLOC_SCRATCH_BYTES (32u << 20)
+#define IPX_NOALLOC_MAX_QUERIES 192
+int ipx_search_noalloc(ipx_index* idx, const float* q, int64_t nq, int k,
+                       float* out_D, int64_t* out_I, void* stream);
+
 /* MURAL multi-aspect query, fused on the device before the scan:
  *   q[i] = sum_a w[i][a] * aspect_emb[i][a][:]        modeling/mul_grain.py:97-110
  * aspect_emb: fp32 [nq, A, d]; w: fp32 [nq, A]. If w_is_logits != 0 the weights are

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libipx.so")
 #: every symbol include/ipx.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "ipx_last_error", "ipx_version", "ipx_device_count", "ipx_create", "ipx_destroy", "ipx_dim",
-    "ipx_ntotal", "ipx_reserve", "ipx_set_id_base", "ipx_add", "ipx_search", "ipx_search_aspect", "ipx_search_pooled", "ipx_pool", "ipx_add_pooled",
+    "ipx_ntotal", "ipx_reserve", "ipx_set_id_base", "ipx_add", "ipx_search", "ipx_search_noalloc", "ipx_search_aspect", "ipx_search_pooled", "ipx_pool", "ipx_add_pooled",
     "ipx_merge_topk", "ipx_set_param", "ipx_read_trace", "ipx_check", "ipx_set_timing", "ipx_last_timing", "ipx_last_geometry",
     "ipx_last_bf16_stats",
     "ipx_write_ranking", "ipx_format_score",
@@ -60,6 +60,7 @@ def lib():
     L.ipx_set_id_base.argtypes = [vp, i64]
     L.ipx_add.argtypes = [vp, vp, i64, i32, i32, vp]
     L.ipx_search.argtypes = [vp, f32p, i64, i32, f32p, i64p, i32, vp]
+    L.ipx_search_noalloc.argtypes = [vp, f32p, i64, i32, f32p, i64p, vp]
     L.ipx_search_aspect.argtypes = [vp, f32p, f32p, i32, i32, i64, i32, f32p, i64p, i32, vp]
     L.ipx_search_pooled.argtypes = [vp, f32p, i64, f32p, f32p, i32, i32, i64, i32, f32p, i64p, f32p, i32, vp]
     L.ipx_pool.argtypes = [vp, f32p, i64, f32p, f32p, i32, i32, i64, f32p, f32p, i32, vp]

@@ -4,22 +4,33 @@
 // and launches the gfx950 kernels. Every entry point cites the reference call it replaces
 // in include/ipx.h. No CPU fallback: without a HIP device every compute call fails with
 // IPX_ERR_HIP.
+#include "../../include/ipx.h"
 #include "ipx_bf16_kernels.h"
 #include "ipx_f32_small_kernels.h"
 #include "ipx_bf16_w16_kernels.h"
 #include "ipx_bf16_pp_kernels.h"
 #include "ipx_bf16_dx_kernels.h"
-#include "../../include/ipx.h"
-
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
 #include <vector>
 
+// Workspace of ipx_search_noalloc (include/ipx.h): device memory that exists from the moment the code object is
+// loaded, so that entry point never allocates. Every GPU the library runs on holds its own copy at its own
+// address until the process ends. In host code this NAME is only a handle for hipGetSymbolAddress — never a
+// device address: the per-device address is resolved once (scratch_ptr below) and only that pointer is handed
+// to kernels, memsets and copies.
+static __device__ __align__(256) unsigned char scratch[IPX_NOALLOC_SCRATCH_BYTES];
+
 namespace {
+
+constexpr int IPX_MAX_DEVICES = 64;
+void* g_scratch_ptr[IPX_MAX_DEVICES] = {};      // address of `scratch` on each device, resolved once
+std::mutex g_scratch_mu;
 
 thread_local std::string g_err;
 
@@ -57,6 +68,33 @@ struct DevBuf {
     }
 };
 
+// Makes `device` current for the duration of a call and restores the caller's device afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+        else if (err != hipSuccess) { prev = -1; err = hipSetDevice(device); }
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// Address of the static workspace on `device` (which must be current). Resolved once per device.
+int scratch_ptr(int device, void** out) {
+    if (device < 0 || device >= IPX_MAX_DEVICES) return fail(IPX_ERR_ARG, "device index beyond " + std::to_string(IPX_MAX_DEVICES));
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr)
+            return fail(IPX_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
+
 int next_pow2(int x) {
     int p = 1;
     while (p < x) p <<= 1;
@@ -68,6 +106,7 @@ int next_pow2(int x) {
 struct ipx_index {
     int d = 0, nks = 0, device = 0;
     int num_cus = 0;         // multiProcessorCount of `device`, read once at create
+    int* last_err = nullptr; // error word of the most recent search (ipx_check reads it)
     int64_t ntotal = 0;
     int64_t cap_tiles = 0;   // tiles of 128 rows the corpus buffer holds
     int64_t id_base = 0;
@@ -224,83 +263,90 @@ int dtype_size(int dtype) { return dtype == IPX_F32 ? 4 : 2; }
 
 struct Geometry { int nqb, ntiles, S, R, G, cap; };
 
-// fp32 scan of a small batch (scan_f32_small_kernel: 32 or 64 queries per workgroup, one workgroup
-// per CU): pack -> scan -> merge. Same scores, bit for bit, as scan_f32_path.
-int scan_f32_small_path(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
-                        float* dD, int64_t* dI, hipStream_t st, bool primary) {
-    const bool record = primary && ix->timing;
-    const int d = ix->d, nks = ix->nks;
-    const int64_t N = ix->ntotal;
-    const size_t nout = (size_t)nq * k;
-    const int qt = nq <= 32 ? 1 : 2;
-    const int bq = 32 * qt;
-    const int nqb = (int)((nq + bq - 1) / bq);
-    const int ntiles = (int)((N + ipx::BD - 1) / ipx::BD);
-    const int resident = 2 * ix->num_cus;                   // two 512-thread workgroups per CU
-    const int npairs = (ntiles + 1) / 2;                    // the kernel steps through pairs of corpus tiles
-    int S = std::max(1, resident / nqb);
-    if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
-    const int R = std::max(2, std::min(32, npairs / (S * 64)));
-    const int nruns = (npairs + R - 1) / R;
-    S = std::min(S, nruns);
-    const int G = nqb * S;
-    // queue: k survivors of a compaction + 2 steps (4 tiles) of appends before the next one runs + room to fill
-    const int cap = next_pow2(k + 4 * ipx::BD + k / 2);
-    const int ring = qt == 1 ? ipx::SCfg<1>::RING : ipx::SCfg<2>::RING;
-    const int nsortwaves = std::max(1, std::min(8, ring / (cap * 8)));
-    const int stage_b = bq * 64;
-
-    if (int rc = ix->Qp.ensure((size_t)nqb * nks * stage_b)) return rc;
-    if (int rc = ix->cand.ensure((size_t)G * bq * cap * sizeof(uint64_t))) return rc;
-    if (int rc = ix->err.ensure(256)) return rc;
-    if (S > 1) {
-        if (int rc = ix->partD.ensure(nout * S * sizeof(float))) return rc;
-        if (int rc = ix->partI.ensure(nout * S * sizeof(int64_t))) return rc;
-        if (int rc = ix->flags.ensure((size_t)nq * sizeof(int))) return rc;
+// ---- fp32 scan of a small batch (scan_f32_small_kernel: 32 or 64 queries per workgroup, two workgroups per CU):
+// pack -> scan -> merge. Same scores, bit for bit, as the large tile. Geometry, workspace and launch are separate
+// so that ipx_search_noalloc can run the same kernels on the static workspace.
+struct SmallGeom {
+    int qt, bq, nqb, ntiles, S, R, G, cap, ring, nsortwaves;
+    size_t qp_bytes, cand_bytes, partD_bytes, partI_bytes, flags_bytes, ctr_bytes, pub_bytes;
+    size_t total() const {      // every buffer rounded up to 256 bytes, + the error word
+        size_t t = 256;
+        for (size_t b : {qp_bytes, cand_bytes, partD_bytes, partI_bytes, flags_bytes, pub_bytes}) t += (b + 255) / 256 * 256;
+        return t;
     }
-    const size_t ctr_bytes = ((size_t)nqb * sizeof(uint32_t) + 255) / 256 * 256;
-    // published bounds: up to IPX_MAX_SUBSPLITS values per split and query (short-list path)
-    const size_t pub_bytes = ctr_bytes + (size_t)G * bq * ipx::IPX_MAX_SUBSPLITS * sizeof(uint32_t);
-    if (int rc = ix->pub.ensure(pub_bytes)) return rc;
-    IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
+};
+struct SmallBufs { void *Qp, *cand, *partD, *partI, *flags, *pub; int* err; };
 
+// `split_cap` > 0 bounds the corpus splits per query block (ipx_set_param "max_splits", or what fits a workspace)
+SmallGeom small_geometry(const ipx_index* ix, int64_t nq, int k, int split_cap) {
+    SmallGeom g;
+    g.qt = nq <= 32 ? 1 : 2;
+    g.bq = 32 * g.qt;
+    g.nqb = (int)((nq + g.bq - 1) / g.bq);
+    g.ntiles = (int)((ix->ntotal + ipx::BD - 1) / ipx::BD);
+    const int resident = 2 * ix->num_cus;                   // two 512-thread workgroups per CU
+    const int npairs = (g.ntiles + 1) / 2;                  // the kernel steps through pairs of corpus tiles
+    int S = std::max(1, resident / g.nqb);
+    if (split_cap > 0) S = std::min(S, split_cap);
+    g.R = std::max(2, std::min(32, npairs / (S * 64)));
+    const int nruns = (npairs + g.R - 1) / g.R;
+    g.S = std::min(S, nruns);
+    g.G = g.nqb * g.S;
+    // queue: k survivors of a compaction + 2 steps (4 tiles) of appends before the next one runs + room to fill
+    g.cap = next_pow2(k + 4 * ipx::BD + k / 2);
+    g.ring = g.qt == 1 ? ipx::SCfg<1>::RING : ipx::SCfg<2>::RING;
+    g.nsortwaves = std::max(1, std::min(8, g.ring / (g.cap * 8)));
+    const size_t nout = (size_t)nq * k;
+    g.qp_bytes = (size_t)g.nqb * ix->nks * g.bq * 64;
+    g.cand_bytes = (size_t)g.G * g.bq * g.cap * sizeof(uint64_t);
+    g.partD_bytes = g.S > 1 ? nout * g.S * sizeof(float) : 0;
+    g.partI_bytes = g.S > 1 ? nout * g.S * sizeof(int64_t) : 0;
+    g.flags_bytes = g.S > 1 ? (size_t)nq * sizeof(int) : 0;
+    g.ctr_bytes = ((size_t)g.nqb * sizeof(uint32_t) + 255) / 256 * 256;
+    // published bounds: up to IPX_MAX_SUBSPLITS values per split and query (short-list path)
+    g.pub_bytes = g.ctr_bytes + (size_t)g.G * g.bq * ipx::IPX_MAX_SUBSPLITS * sizeof(uint32_t);
+    return g;
+}
+
+// Launches only: no allocation, no synchronisation. `record`: HIP events around the kernels (ipx_set_timing).
+int scan_f32_small_launch(ipx_index* ix, const SmallGeom& g, const SmallBufs& b, const float* dq, const float* dw, int A,
+                          int logits, int64_t nq, int k, float* dD, int64_t* dI, hipStream_t st, bool record, bool primary) {
+    const int S = g.S;
+    IPX_HIP(hipMemsetAsync(b.pub, 0, g.pub_bytes, st));
     if (record) IPX_HIP(hipEventRecord(ix->ev[0], st));
-    if (int rc = launch_pack(dq, IPX_F32, nq, (int64_t)nqb * bq, d, (float*)ix->Qp.p, 0, bq, nks, dw, A, logits, st))
+    if (int rc = launch_pack(dq, IPX_F32, nq, (int64_t)g.nqb * g.bq, ix->d, (float*)b.Qp, 0, g.bq, ix->nks, dw, A, logits, st))
         return rc;
     if (record) IPX_HIP(hipEventRecord(ix->ev[1], st));
 
     ipx::ScanParams p;
     p.Xp = ix->Xp;
-    p.Qp = (const float*)ix->Qp.p;
-    p.cand = (uint64_t*)ix->cand.p;
-    p.outD = S > 1 ? (float*)ix->partD.p : dD;
-    p.outI = S > 1 ? (int64_t*)ix->partI.p : dI;
-    p.err = (int*)ix->err.p;
-    p.run_ctr = (uint32_t*)ix->pub.p;
-    p.pub = (uint32_t*)((char*)ix->pub.p + ctr_bytes);
-    p.run_tiles = R;
+    p.Qp = (const float*)b.Qp;
+    p.cand = (uint64_t*)b.cand;
+    p.outD = S > 1 ? (float*)b.partD : dD;
+    p.outI = S > 1 ? (int64_t*)b.partI : dI;
+    p.err = b.err;
+    p.run_ctr = (uint32_t*)b.pub;
+    p.pub = (uint32_t*)((char*)b.pub + g.ctr_bytes);
+    p.run_tiles = g.R;
     p.r = (k + S - 1) / S;
     p.trace = nullptr;
-    if (ix->trace_on) {
-        if (int rc = ix->trace.ensure((size_t)G * 20 * sizeof(uint64_t))) return rc;
-        p.trace = (uint64_t*)ix->trace.p;
-    }
-    p.N = N;
+    if (ix->trace_on && ix->trace.bytes >= (size_t)g.G * 20 * sizeof(uint64_t)) p.trace = (uint64_t*)ix->trace.p;
+    p.N = ix->ntotal;
     p.id_base = ix->id_base;
     p.nq = (int)nq;
-    p.nks = nks;
+    p.nks = ix->nks;
     p.k = k;
-    p.cap = cap;
+    p.cap = g.cap;
     p.S = S;
     p.S_out = S;
     p.helpers = 0;
     p.help_ctr = nullptr;
-    p.ntiles = ntiles;
-    const int lds = std::max(ring, nsortwaves * cap * 8) + ipx::LDS_STATE_BYTES;
+    p.ntiles = g.ntiles;
+    const int lds = std::max(g.ring, g.nsortwaves * g.cap * 8) + ipx::LDS_STATE_BYTES;
     {
-        void (*kern)(const ipx::ScanParams, const int) = qt == 1 ? ipx::scan_f32_small_kernel<1> : ipx::scan_f32_small_kernel<2>;
+        void (*kern)(const ipx::ScanParams, const int) = g.qt == 1 ? ipx::scan_f32_small_kernel<1> : ipx::scan_f32_small_kernel<2>;
         IPX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(kern, dim3(G), dim3(512), lds, st, p, nsortwaves);
+        hipLaunchKernelGGL(kern, dim3(g.G), dim3(512), lds, st, p, g.nsortwaves);
     }
     IPX_HIP(hipGetLastError());
     if (record) IPX_HIP(hipEventRecord(ix->ev[2], st));
@@ -315,13 +361,13 @@ int scan_f32_small_path(ipx_index* ix, const float* dq, const float* dw, int A, 
         // queries whose pool overflowed
         const int* todo = nullptr;
         if (S >= 16) {
-            hipLaunchKernelGGL(ipx::merge_pool_kernel, dim3((unsigned)nq), dim3(256), 0, st, (const float*)ix->partD.p,
-                               (const int64_t*)ix->partI.p, S, k, k, (int64_t)k, (int64_t)S * k, dD, dI, (int*)ix->flags.p);
+            hipLaunchKernelGGL(ipx::merge_pool_kernel, dim3((unsigned)nq), dim3(256), 0, st, (const float*)b.partD,
+                               (const int64_t*)b.partI, S, k, k, (int64_t)k, (int64_t)S * k, dD, dI, (int*)b.flags);
             IPX_HIP(hipGetLastError());
-            todo = (const int*)ix->flags.p;
+            todo = (const int*)b.flags;
         }
         hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st,
-                           (const float*)ix->partD.p, (const int64_t*)ix->partI.p, S, nq, k, k, P, 1,
+                           (const float*)b.partD, (const int64_t*)b.partI, S, nq, k, k, P, 1,
                            (int64_t)k, (int64_t)S * k, dD, dI, todo);
         IPX_HIP(hipGetLastError());
         if (record) {
@@ -330,12 +376,30 @@ int scan_f32_small_path(ipx_index* ix, const float* dq, const float* dw, int A, 
         }
     }
     if (primary) {
-        ix->ev_valid = ix->timing;
-        ix->last_wgs = G;
+        ix->ev_valid = record;
+        ix->last_wgs = g.G;
         ix->last_S = S;
-        ix->last_cap = cap;
+        ix->last_cap = g.cap;
     }
     return 0;
+}
+
+int scan_f32_small_path(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
+                        float* dD, int64_t* dI, hipStream_t st, bool primary) {
+    const SmallGeom g = small_geometry(ix, nq, k, ix->max_splits);
+    if (int rc = ix->Qp.ensure(g.qp_bytes)) return rc;
+    if (int rc = ix->cand.ensure(g.cand_bytes)) return rc;
+    if (int rc = ix->err.ensure(256)) return rc;
+    if (g.S > 1) {
+        if (int rc = ix->partD.ensure(g.partD_bytes)) return rc;
+        if (int rc = ix->partI.ensure(g.partI_bytes)) return rc;
+        if (int rc = ix->flags.ensure(g.flags_bytes)) return rc;
+    }
+    if (int rc = ix->pub.ensure(g.pub_bytes)) return rc;
+    if (ix->trace_on)
+        if (int rc = ix->trace.ensure((size_t)g.G * 20 * sizeof(uint64_t))) return rc;
+    const SmallBufs b{ix->Qp.p, ix->cand.p, ix->partD.p, ix->partI.p, ix->flags.p, ix->pub.p, (int*)ix->err.p};
+    return scan_f32_small_launch(ix, g, b, dq, dw, A, logits, nq, k, dD, dI, st, primary && ix->timing, primary);
 }
 
 // fp32 scan of nq row-major fp32 queries already on the device (A > 0: aspect embeddings + weights,
@@ -784,6 +848,7 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
     } else {
         if (int rc = ix->err.ensure(256)) return rc;
         IPX_HIP(hipMemsetAsync(ix->err.p, 0, 256, st));
+        ix->last_err = (int*)ix->err.p;
         // bf16 scan whenever the index keeps a bf16 copy and the candidate list (2k with hi + lo
         // query parts, 1.25k on bf16 rows) fits IPX_MAX_K; deeper searches take the fp32 scan,
         // which bf16-only storage does not have
@@ -846,6 +911,17 @@ int ipx_create(int d, int device, ipx_index** out) {
         return fail(IPX_ERR_HIP, std::string("create: multiprocessor count: ") + hipGetErrorString(e));
     }
     ix->num_cus = cus;
+    {   // set-up of the no-allocation workspace: once per device, with that device current
+        DeviceGuard guard(device);
+        void* ws = nullptr;
+        int rc = guard.err != hipSuccess
+                     ? fail(IPX_ERR_HIP, std::string("create: hipSetDevice: ") + hipGetErrorString(guard.err))
+                     : scratch_ptr(device, &ws);
+        if (rc) {
+            delete ix;
+            return rc;
+        }
+    }
     *out = ix;
     return 0;
 }
@@ -952,6 +1028,62 @@ int ipx_add(ipx_index* ix, const void* rows, int64_t n, int dtype, int on_device
 int ipx_search(ipx_index* ix, const float* q, int64_t nq, int k, float* out_D, int64_t* out_I, int on_device,
                void* stream) {
     return search_impl(ix, q, nullptr, 0, 0, nq, k, out_D, out_I, on_device, stream);
+}
+
+// The one entry point that allocates nothing: ipx_search on device pointers, small batches, fp32 rows, with every
+// intermediate buffer (packed queries, candidate queues, per-split lists, counters, the error word) carved from the
+// static workspace `scratch`. No hipMalloc / hipFree / event creation; stream-ordered, returns without synchronising.
+int ipx_search_noalloc(ipx_index* ix, const float* q, int64_t nq, int k, float* out_D, int64_t* out_I, void* stream) {
+    if (!ix) return fail(IPX_ERR_ARG, "search_noalloc: null index");
+    if (nq < 0 || nq > IPX_NOALLOC_MAX_QUERIES)
+        return fail(IPX_ERR_ARG, "search_noalloc: nq=" + std::to_string(nq) + " outside [0, " +
+                    std::to_string(IPX_NOALLOC_MAX_QUERIES) + "] (use ipx_search for larger batches)");
+    if (k <= 0 || k > IPX_MAX_K)
+        return fail(IPX_ERR_ARG, "search_noalloc: k=" + std::to_string(k) + " outside [1, " + std::to_string(IPX_MAX_K) + "]");
+    if (ix->storage == 2) return fail(IPX_ERR_STATE, "search_noalloc: needs fp32 rows (storage 0 or 1)");
+    if (nq == 0) return 0;
+    if (!q || !out_D || !out_I) return fail(IPX_ERR_ARG, "search_noalloc: null pointer");
+    DeviceGuard guard(ix->device);
+    if (guard.err != hipSuccess) return fail(IPX_ERR_HIP, std::string("search_noalloc: hipSetDevice: ") + hipGetErrorString(guard.err));
+    hipStream_t st = (hipStream_t)stream;
+    ix->ev_valid = ix->ev_merge = ix->ev_rescore = false;
+    ix->last_kc = 0;
+    ix->last_fallback = 0;
+    if (ix->ntotal == 0) {
+        const int64_t nout = nq * k;
+        hipLaunchKernelGGL(ipx::fill_empty_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, out_D, out_I, nout);
+        IPX_HIP(hipGetLastError());
+        ix->last_err = nullptr;
+        return 0;
+    }
+    void* ws = nullptr;
+    if (int rc = scratch_ptr(ix->device, &ws)) return rc;
+    // as many corpus splits as the workspace holds (each split brings its candidate queues and its partial lists)
+    SmallGeom g = small_geometry(ix, nq, k, ix->max_splits);
+    while (g.total() > (size_t)IPX_NOALLOC_SCRATCH_BYTES && g.S > 1) {
+        const int fit = (int)((double)g.S * IPX_NOALLOC_SCRATCH_BYTES / (double)g.total());
+        g = small_geometry(ix, nq, k, std::max(1, std::min(g.S - 1, fit)));
+    }
+    if (g.total() > (size_t)IPX_NOALLOC_SCRATCH_BYTES)
+        return fail(IPX_ERR_ARG, "search_noalloc: nq=" + std::to_string(nq) + ", k=" + std::to_string(k) + ", d=" +
+                    std::to_string(ix->d) + " need " + std::to_string(g.total()) + " bytes of workspace, more than the " +
+                    std::to_string((size_t)IPX_NOALLOC_SCRATCH_BYTES) + " this entry point owns (use ipx_search)");
+    char* at = (char*)ws;
+    auto carve = [&](size_t bytes) { char* r = at; at += (bytes + 255) / 256 * 256; return (void*)r; };
+    SmallBufs b;
+    b.err = (int*)carve(256);
+    b.Qp = carve(g.qp_bytes);
+    b.cand = carve(g.cand_bytes);
+    b.partD = carve(g.partD_bytes);
+    b.partI = carve(g.partI_bytes);
+    b.flags = carve(g.flags_bytes);
+    b.pub = carve(g.pub_bytes);
+    // the workspace keeps the previous call's contents: what must start at zero is cleared here (the error word)
+    // and in the launch (run counters and published bounds); queues, lists and flags are written before they are read
+    IPX_HIP(hipMemsetAsync(b.err, 0, 256, st));
+    ix->last_err = b.err;
+    const bool record = ix->timing && ix->ev[0] != nullptr;     // events are never created here
+    return scan_f32_small_launch(ix, g, b, q, nullptr, 0, 0, nq, k, out_D, out_I, st, record, true);
 }
 
 int ipx_search_aspect(ipx_index* ix, const float* aspect_emb, const float* w, int A, int w_is_logits, int64_t nq,
@@ -1191,7 +1323,7 @@ int ipx_check(ipx_index* ix, void* stream) {
     IPX_HIP(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;
     int errflag = 0;
-    if (ix->err.p) IPX_HIP(hipMemcpyAsync(&errflag, ix->err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (ix->last_err) IPX_HIP(hipMemcpyAsync(&errflag, ix->last_err, sizeof(int), hipMemcpyDeviceToHost, st));
     IPX_HIP(hipStreamSynchronize(st));
     if (errflag) return fail(IPX_ERR_STATE, "search: candidate queue overflow (internal invariant violated)");
     return 0;
