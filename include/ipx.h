@@ -199,6 +199,17 @@ int ipx_write_ranking(const char* path, const uint32_t* qids, int qid_width,
                       const uint32_t* docids, int docid_width, const int64_t* docids_i64,
                       const float* scores, int64_t nq, int k);
 
+/* The same file straight from what the search returns            __main__.py:27-28 + :32-38
+ * (search_queries' id mapping and write_ranking's loop in one pass, for text output): `rows` int64 [nq*k] are
+ * positions in the CLI's lookup list, whose entries arrive as one UTF-8 blob: entry r is
+ * doc_blob[doc_offsets[r] .. doc_offsets[r+1] - sep) (n_docs + 1 offsets; sep = bytes of separator behind every
+ * entry, 0 or more: "\n".join(ids) is such a blob with sep = 1). Negative rows count from the end, as the
+ * reference's list indexing does (a -1 padding id names the last document); rows outside [-n_docs, n_docs) are
+ * IPX_ERR_ARG ("list index out of range"). The [nq, k] array of id strings is never built. */
+int ipx_write_ranking_lookup(const char* path, const uint32_t* qids, int qid_width, const char* doc_blob,
+                             const int64_t* doc_offsets, int sep, int64_t n_docs, const int64_t* rows,
+                             const float* scores, int64_t nq, int k);
+
 /* Python repr(float(np.float32(x))) into buf (>= 32 bytes). Returns the length. */
 int ipx_format_score(float x, char* buf, size_t buflen);
 

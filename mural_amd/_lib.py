@@ -15,7 +15,7 @@ SYMBOLS = [
     "ipx_ntotal", "ipx_reserve", "ipx_set_id_base", "ipx_add", "ipx_search", "ipx_search_noalloc", "ipx_search_aspect", "ipx_search_pooled", "ipx_pool", "ipx_add_pooled",
     "ipx_merge_topk", "ipx_set_param", "ipx_read_trace", "ipx_check", "ipx_set_timing", "ipx_last_timing", "ipx_last_geometry",
     "ipx_last_bf16_stats",
-    "ipx_write_ranking", "ipx_format_score",
+    "ipx_write_ranking", "ipx_write_ranking_lookup", "ipx_format_score",
 ]
 
 IPX_F32, IPX_F16, IPX_BF16 = 0, 1, 2
@@ -74,6 +74,7 @@ def lib():
     L.ipx_last_geometry.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.ipx_last_bf16_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32), C.POINTER(i64)]
     L.ipx_write_ranking.argtypes = [C.c_char_p, vp, i32, vp, i32, vp, vp, i64, i32]
+    L.ipx_write_ranking_lookup.argtypes = [C.c_char_p, vp, i32, vp, vp, i32, i64, vp, vp, i64, i32]
     L.ipx_format_score.argtypes = [C.c_float, C.c_char_p, C.c_size_t]
     _lib = L
     return L

@@ -12,6 +12,7 @@
 #include "../../include/ipx.h"
 
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdio>
@@ -130,6 +131,95 @@ inline char* put_i64(char* p, int64_t v) {
 
 }  // namespace
 
+namespace {
+
+// Shared body of the two writers: `put_doc(p, i, h)` appends the doc id of hit h of query i; `doc_max` bounds its
+// UTF-8 length. Never throws: an allocation failure in a formatting thread becomes IPX_ERR_NOMEM.
+template <class PutDoc>
+int write_ranking_impl(const char* path, const uint32_t* qids, int qid_width, size_t doc_max, PutDoc put_doc,
+                       const float* scores, int64_t nq, int k) {
+    FILE* f = fopen(path, "w");
+    if (!f) {
+        ipx_set_error_((std::string("write_ranking: cannot open ") + path).c_str());
+        return IPX_ERR_IO;
+    }
+    const size_t line_max = 4 * (size_t)qid_width + doc_max + 48;
+    // Queries are formatted in blocks by a few threads (sorting + shortest-round-trip float printing is
+    // the cost: 7M lines at depth 1000), and the blocks are written in order by this thread.
+    const int64_t block = std::max<int64_t>(1, std::min<int64_t>(256, (int64_t)((4u << 20) / (line_max * (size_t)(k > 0 ? k : 1) + 1))));
+    int nthreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    if (const char* e = std::getenv("IPX_WRITER_THREADS")) nthreads = std::max(1, std::min(64, std::atoi(e)));
+    std::atomic<bool> nomem{false};
+    auto format_block = [&](int64_t q0, int64_t q1, std::vector<char>& out) {
+        try {
+            out.resize((size_t)(q1 - q0) * line_max * (size_t)(k > 0 ? k : 1) + 64);
+            std::vector<int> order(k);
+            char* p = out.data();
+            for (int64_t i = q0; i < q1; ++i) {
+                const float* s = scores + i * k;
+                std::iota(order.begin(), order.end(), 0);
+                // stable, descending by score only (ties keep input order, as Python's sorted does)
+                std::stable_sort(order.begin(), order.end(), [s](int a, int b) {
+                    const float x = std::isnan(s[a]) ? -INFINITY : s[a];
+                    const float y = std::isnan(s[b]) ? -INFINITY : s[b];
+                    return x > y;
+                });
+                for (int j = 0; j < k; ++j) {
+                    const int h = order[j];
+                    p = put_ucs4(p, qids + i * qid_width, qid_width);
+                    *p++ = '\t';
+                    p = put_doc(p, i, h);
+                    *p++ = '\t';
+                    p += py_float_repr((double)s[h], p);
+                    *p++ = '\n';
+                }
+            }
+            out.resize((size_t)(p - out.data()));
+        } catch (...) {             // bad_alloc: reported, the process lives on
+            out.clear();
+            nomem = true;
+        }
+    };
+    bool ok = true;
+    try {
+        std::vector<std::vector<char>> bufs((size_t)nthreads);
+        for (int64_t q0 = 0; q0 < nq && ok && !nomem; q0 += block * nthreads) {
+            std::vector<std::thread> th;
+            int used_bufs = 0;
+            for (int t = 0; t < nthreads; ++t) {
+                const int64_t b0 = q0 + t * block, b1 = std::min(nq, b0 + block);
+                if (b0 >= nq) break;
+                ++used_bufs;
+                if (nthreads == 1 || nq <= block) format_block(b0, b1, bufs[(size_t)t]);
+                else {
+                    try {
+                        th.emplace_back(format_block, b0, b1, std::ref(bufs[(size_t)t]));
+                    } catch (...) {                 // no thread to be had: format here
+                        format_block(b0, b1, bufs[(size_t)t]);
+                    }
+                }
+            }
+            for (auto& t : th) t.join();
+            for (int t = 0; t < used_bufs && ok && !nomem; ++t)
+                ok = bufs[(size_t)t].empty() || fwrite(bufs[(size_t)t].data(), 1, bufs[(size_t)t].size(), f) == bufs[(size_t)t].size();
+        }
+    } catch (...) {
+        nomem = true;
+    }
+    if (fclose(f) != 0) ok = false;
+    if (nomem) {
+        ipx_set_error_("write_ranking: out of host memory while formatting");
+        return IPX_ERR_NOMEM;
+    }
+    if (!ok) {
+        ipx_set_error_((std::string("write_ranking: write failed on ") + path).c_str());
+        return IPX_ERR_IO;
+    }
+    return 0;
+}
+
+}  // namespace
+
 extern "C" int ipx_write_ranking(const char* path, const uint32_t* qids, int qid_width, const uint32_t* docids,
                                  int docid_width, const int64_t* docids_i64, const float* scores, int64_t nq,
                                  int k) {
@@ -138,63 +228,38 @@ extern "C" int ipx_write_ranking(const char* path, const uint32_t* qids, int qid
         ipx_set_error_("write_ranking: bad argument");
         return IPX_ERR_ARG;
     }
-    FILE* f = fopen(path, "w");
-    if (!f) {
-        ipx_set_error_((std::string("write_ranking: cannot open ") + path).c_str());
-        return IPX_ERR_IO;
+    if (docids)
+        return write_ranking_impl(path, qids, qid_width, 4 * (size_t)docid_width,
+                                  [=](char* p, int64_t i, int h) { return put_ucs4(p, docids + ((size_t)i * k + h) * docid_width, docid_width); },
+                                  scores, nq, k);
+    return write_ranking_impl(path, qids, qid_width, 24,
+                              [=](char* p, int64_t i, int h) { return put_i64(p, docids_i64[(size_t)i * k + h]); }, scores, nq, k);
+}
+
+extern "C" int ipx_write_ranking_lookup(const char* path, const uint32_t* qids, int qid_width, const char* doc_blob,
+                                        const int64_t* doc_offsets, int sep, int64_t n_docs, const int64_t* rows,
+                                        const float* scores, int64_t nq, int k) {
+    if (!path || nq < 0 || k < 0 || qid_width < 0 || n_docs < 0 || sep < 0 ||
+        (nq > 0 && (!qids || (k > 0 && (!rows || !scores || !doc_offsets || (!doc_blob && n_docs > 0)))))) {
+        ipx_set_error_("write_ranking_lookup: bad argument");
+        return IPX_ERR_ARG;
     }
-    const size_t line_max = 4 * (size_t)qid_width + (docids ? 4 * (size_t)docid_width : 24) + 48;
-    // Queries are formatted in blocks by a few threads (sorting + shortest-round-trip float printing is
-    // the cost: 7M lines at depth 1000), and the blocks are written in order by this thread.
-    const int64_t block = std::max<int64_t>(1, std::min<int64_t>(256, (int64_t)((4u << 20) / (line_max * (size_t)(k > 0 ? k : 1) + 1))));
-    int nthreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-    if (const char* e = std::getenv("IPX_WRITER_THREADS")) nthreads = std::max(1, std::min(64, std::atoi(e)));
-    auto format_block = [&](int64_t q0, int64_t q1, std::vector<char>& out) {
-        out.resize((size_t)(q1 - q0) * line_max * (size_t)(k > 0 ? k : 1) + 64);
-        std::vector<int> order(k);
-        char* p = out.data();
-        for (int64_t i = q0; i < q1; ++i) {
-            const float* s = scores + i * k;
-            std::iota(order.begin(), order.end(), 0);
-            // stable, descending by score only (ties keep input order, as Python's sorted does)
-            std::stable_sort(order.begin(), order.end(), [s](int a, int b) {
-                const float x = std::isnan(s[a]) ? -INFINITY : s[a];
-                const float y = std::isnan(s[b]) ? -INFINITY : s[b];
-                return x > y;
-            });
-            for (int j = 0; j < k; ++j) {
-                const int h = order[j];
-                p = put_ucs4(p, qids + i * qid_width, qid_width);
-                *p++ = '\t';
-                if (docids) p = put_ucs4(p, docids + ((size_t)i * k + h) * docid_width, docid_width);
-                else p = put_i64(p, docids_i64[(size_t)i * k + h]);
-                *p++ = '\t';
-                p += py_float_repr((double)s[h], p);
-                *p++ = '\n';
-            }
-        }
-        out.resize((size_t)(p - out.data()));
-    };
-    std::vector<std::vector<char>> bufs((size_t)nthreads);
-    bool ok = true;
-    for (int64_t q0 = 0; q0 < nq && ok; q0 += block * nthreads) {
-        std::vector<std::thread> th;
-        int used_bufs = 0;
-        for (int t = 0; t < nthreads; ++t) {
-            const int64_t b0 = q0 + t * block, b1 = std::min(nq, b0 + block);
-            if (b0 >= nq) break;
-            ++used_bufs;
-            if (nthreads == 1 || nq <= block) format_block(b0, b1, bufs[(size_t)t]);
-            else th.emplace_back(format_block, b0, b1, std::ref(bufs[(size_t)t]));
-        }
-        for (auto& t : th) t.join();
-        for (int t = 0; t < used_bufs && ok; ++t)
-            ok = bufs[(size_t)t].empty() || fwrite(bufs[(size_t)t].data(), 1, bufs[(size_t)t].size(), f) == bufs[(size_t)t].size();
+    // every hit must name a row of the table (negative rows count from the end, as list indexing in the
+    // reference does: __main__.py:27); the longest id bounds a line
+    size_t doc_max = 0;
+    for (int64_t r = 0; r < n_docs; ++r) {
+        if (doc_offsets[r + 1] - sep < doc_offsets[r]) { ipx_set_error_("write_ranking_lookup: offsets not ascending"); return IPX_ERR_ARG; }
+        doc_max = std::max(doc_max, (size_t)(doc_offsets[r + 1] - sep - doc_offsets[r]));
     }
-    if (fclose(f) != 0) ok = false;
-    if (!ok) {
-        ipx_set_error_((std::string("write_ranking: write failed on ") + path).c_str());
-        return IPX_ERR_IO;
-    }
-    return 0;
+    for (int64_t e = 0; e < nq * (int64_t)k; ++e)
+        if (rows[e] >= n_docs || rows[e] < -n_docs) { ipx_set_error_("write_ranking_lookup: list index out of range"); return IPX_ERR_ARG; }
+    return write_ranking_impl(path, qids, qid_width, doc_max,
+                              [=](char* p, int64_t i, int h) {
+                                  int64_t r = rows[(size_t)i * k + h];
+                                  if (r < 0) r += n_docs;
+                                  const size_t len = (size_t)(doc_offsets[r + 1] - sep - doc_offsets[r]);
+                                  memcpy(p, doc_blob + doc_offsets[r], len);
+                                  return p + len;
+                              },
+                              scores, nq, k);
 }

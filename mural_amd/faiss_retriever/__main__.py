@@ -102,6 +102,50 @@ def write_ranking(corpus_indices, corpus_scores, q_lookup, ranking_save_file):
         C.c_void_p(scores.ctypes.data), nq, k))
 
 
+def _lookup_blob(p_lookup):
+    """The lookup list as one UTF-8 blob + offsets (entry r = blob[off[r]:off[r+1] - 1], a newline behind every entry
+    but the last) for ipx_write_ranking_lookup, or None when an entry's text holds a newline itself."""
+    try:
+        text = "\n".join(p_lookup)                       # all str: one C-level join
+    except TypeError:
+        text = "\n".join(map(str, p_lookup))
+    joined = text.encode("utf-8")
+    n = len(p_lookup)
+    seps = np.flatnonzero(np.frombuffer(joined, dtype=np.uint8) == 10)
+    if seps.size != max(n - 1, 0):
+        return None
+    off = np.empty(n + 1, dtype=np.int64)
+    off[0] = 0
+    off[1:n] = seps + 1
+    off[n] = len(joined) + 1                               # as if a separator followed the last entry too
+    return joined, off
+
+
+def _write_ranking_from_rows(p_lookup, all_indices, all_scores, q_lookup, ranking_save_file):
+    """search_queries' id mapping + write_ranking in one pass (text output of the CLI): the ranking file straight
+    from the row ids the search returned, byte for byte what write_ranking(_lookup_strings(...), ...) writes.
+    Returns False when the inputs are not of the kind the C writer takes (the caller then goes the long way)."""
+    scores, rows = np.asarray(all_scores), np.asarray(all_indices)
+    n = len(p_lookup)
+    if not (scores.dtype == np.float32 and scores.ndim == 2 and rows.shape == scores.shape and rows.dtype == np.int64
+            and scores.size > 0 and n > 0):
+        return False
+    if (rows >= n).any() or (rows < -n).any():
+        raise IndexError("list index out of range")
+    nq = min(len(q_lookup), scores.shape[0])
+    qids = np.array([str(q) for q in q_lookup[:nq]]) if nq else np.array([], dtype="<U1")
+    table = _lookup_blob(p_lookup)
+    if qids.dtype.kind != "U" or table is None:
+        return False
+    blob, off = table
+    scores = np.ascontiguousarray(scores[:nq])
+    rows = np.ascontiguousarray(rows[:nq])
+    _lib.check(_lib.lib().ipx_write_ranking_lookup(
+        str(ranking_save_file).encode(), C.c_void_p(qids.ctypes.data), qids.dtype.itemsize // 4, blob,
+        C.c_void_p(off.ctypes.data), 1, n, C.c_void_p(rows.ctypes.data), C.c_void_p(scores.ctypes.data), nq, scores.shape[1]))
+    return True
+
+
 class _PayloadSkippingReader:
     """File wrapper for pickle.Unpickler that does not read large byte payloads: a request of
     >= `threshold` bytes (the raw data of an ndarray: pickle writes it unframed and the C unpickler
@@ -288,34 +332,90 @@ def _main_sharded(args, engine_factory=None):
             k = args.depth
             all_scores = np.concatenate(all_scores) if all_scores else np.empty((0, k), np.float32)
             all_indices = np.concatenate(all_indices) if all_indices else np.empty((0, k), np.int64)
-            psg_indices = _lookup_strings(look_up, all_indices)
             if args.save_text:
-                write_ranking(psg_indices, all_scores, q_lookup, args.save_ranking_to)
+                if not _write_ranking_from_rows(look_up, all_indices, all_scores, q_lookup, args.save_ranking_to):
+                    write_ranking(_lookup_strings(look_up, all_indices), all_scores, q_lookup, args.save_ranking_to)
             else:
-                pickle_save((all_scores, psg_indices), args.save_ranking_to)
+                pickle_save((all_scores, _lookup_strings(look_up, all_indices)), args.save_ranking_to)
         dist.barrier()
     finally:
         if own_group:
             dist.destroy_process_group()
 
 
+def _is_rank_of_a_launch():
+    """True inside a process that torch.distributed.run (or _spawn_ranks below) started as one rank of several: the
+    rendezvous variables must all be there. A stray WORLD_SIZE alone (a batch scheduler's, say) does not switch the
+    CLI to the distributed path — the reference ignores that variable."""
+    env = os.environ
+    return int(env.get("WORLD_SIZE", "1") or 1) > 1 and "RANK" in env and "MASTER_PORT" in env
+
+
+def _spawn_ranks(argv, n_ranks, entry=None):
+    """One command for N GPUs (IPX_GPUS=N): start N fresh processes, one per GPU, each running this CLI as a rank
+    of a torch.distributed group (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set in their environment), wait for
+    them, return the first non-zero exit status. The parent never touches the GPU: it only imports, parses the
+    arguments and waits. `entry` is the command prefix of a rank (tests inject a CPU engine through it)."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    entry = entry or [sys.executable, "-m", "mural_amd.faiss_retriever"]
+    procs = []
+    for rank in range(n_ranks):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), IPX_GPUS="1")
+        procs.append(subprocess.Popen(entry + list(argv), env=env))
+    status = 0
+    try:
+        for proc in procs:
+            rc = proc.wait()
+            if rc != 0 and status == 0:
+                status = rc
+                for other in procs:           # a rank failed: the others would wait in a collective for ever
+                    if other.poll() is None:
+                        other.terminate()
+    finally:
+        for proc in procs:
+            if proc.poll() is None:
+                proc.kill()
+    return status
+
+
 def main(argv=None):
+    import sys
     args = _parse_args(argv)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if _is_rank_of_a_launch():
         return _main_sharded(args)
+    n_gpus = int(os.environ.get("IPX_GPUS", "1") or 1)
+    if n_gpus > 1:
+        # the reference's command line, unchanged, on N GPUs of this node (src/pretrain_finetune1.sh:218-228)
+        status = _spawn_ranks(sys.argv[1:] if argv is None else argv, n_gpus)
+        if status != 0:
+            raise SystemExit(status)
+        return
     retriever, look_up = _load_index(args.passage_reps)
 
     q_reps, q_lookup = pickle_load(args.query_reps)
     q_reps = q_reps.astype('float32')
 
     logger.info('Index Search Start')
+    if args.save_text:
+        # text output: the row ids go straight to the writer together with the lookup table; the [nq, depth]
+        # array of id strings that search_queries builds is only needed for the pickle output
+        if args.batch_size > 0:
+            all_scores, all_indices = retriever.batch_search(q_reps, args.depth, args.batch_size, args.quiet)
+        else:
+            all_scores, all_indices = retriever.search(q_reps, args.depth)
+        logger.info('Index Search Finished')
+        if not _write_ranking_from_rows(look_up, all_indices, all_scores, q_lookup, args.save_ranking_to):
+            write_ranking(_lookup_strings(look_up, all_indices), all_scores, q_lookup, args.save_ranking_to)
+        return
     all_scores, psg_indices = search_queries(retriever, q_reps, look_up, args)
     logger.info('Index Search Finished')
-
-    if args.save_text:
-        write_ranking(psg_indices, all_scores, q_lookup, args.save_ranking_to)
-    else:
-        pickle_save((all_scores, psg_indices), args.save_ranking_to)
+    pickle_save((all_scores, psg_indices), args.save_ranking_to)
 
 
 if __name__ == '__main__':

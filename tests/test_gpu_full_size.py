@@ -61,6 +61,26 @@ def test_headline_corpus_8p8m_fp32(R):
     D2, I2 = ix.search_device(Q, 100)
     assert ix.last_bf16_stats()["candidates"] > 0
     assert torch.equal(I, I2) and torch.equal(D.view(torch.int32), D2.view(torch.int32))
+    # (2b) the other large-batch bf16 scan kernels at full size (ping-pong, direct corpus operand): the same bits
+    for pp in (1, 3):
+        ix.set_param("bf16_pp", pp)
+        D2b, I2b = ix.search_device(Q, 100)
+        assert ix.last_bf16_stats()["candidates"] > 0
+        assert torch.equal(I, I2b) and torch.equal(D.view(torch.int32), D2b.view(torch.int32)), pp
+    ix.set_param("bf16_pp", 0)
+    # (2c) configs[2]'s own depth, top-1000: the fp32 scan and the bf16 scan (hi + lo query parts) agree bit for
+    #      bit, and top-100 is its prefix
+    ix.set_param("f32_scan", 1)
+    Dk, Ik = ix.search_device(Q, 1000)
+    ix.check()
+    assert bool((Dk[:, :-1] >= Dk[:, 1:]).all()) and int(Ik.min()) >= 0 and int(Ik.max()) < n
+    assert torch.equal(Ik[:, :100], I) and torch.equal(Dk[:, :100].contiguous().view(torch.int32), D.view(torch.int32))
+    ix.set_param("f32_scan", 0)
+    Dk2, Ik2 = ix.search_device(Q, 1000)
+    st = ix.last_bf16_stats()
+    assert st["candidates"] == 2000 and st["fallback_queries"] < nq // 50
+    assert torch.equal(Ik, Ik2) and torch.equal(Dk.view(torch.int32), Dk2.view(torch.int32))
+    del Dk, Ik, Dk2, Ik2
     # (3) small batches on the fp32 rows (scan_f32_small_kernel) and on the bf16 copy: the same bits again,
     #     and top-10 is the prefix of top-100
     for bnq in (1, 16, 64, 150):

@@ -77,6 +77,57 @@ def test_write_ranking_golden(golden, tmp_path):
                           golden["A2_expected"])
 
 
+def _ranking_from_rows(lookup, rows, scores, qlookup, tmp_path):
+    p = tmp_path / "rank_rows.txt"
+    assert drv._write_ranking_from_rows(lookup, rows, scores, qlookup, str(p))
+    return np.frombuffer(p.read_bytes(), dtype=np.uint8)
+
+
+def test_write_ranking_from_rows_golden(golden, tmp_path):
+    """The CLI's text output goes from row ids to the file in one C pass (ipx_write_ranking_lookup): the golden
+    bytes of the reference's lookup + write_ranking loops (__main__.py:27-38) for the same hits."""
+    ql = ["q1", 17, "query-é"]
+    s = golden["A_scores"]
+    for ids, exp in ((golden["A_ids_str"], "A_expected_str"), (golden["A_ids_int"], "A_expected_int")):
+        uniq, rows = np.unique(ids, return_inverse=True)
+        lookup = uniq.tolist()                              # str entries / int entries (str() applied by the writer)
+        rows = rows.reshape(ids.shape).astype(np.int64)
+        assert np.array_equal(_ranking_from_rows(lookup, rows, s, ql, tmp_path), golden[exp])
+        # negative rows index from the end, as list indexing does in the reference
+        assert np.array_equal(_ranking_from_rows(lookup, rows - len(lookup), s, ql, tmp_path), golden[exp])
+    uniq, rows = np.unique(golden["A_ids_str"], return_inverse=True)
+    rows = rows.reshape(s.shape).astype(np.int64)
+    assert np.array_equal(_ranking_from_rows(uniq.tolist(), rows, s, ql[:2], tmp_path), golden["A_expected_short_q"])
+    assert np.array_equal(_ranking_from_rows(uniq.tolist(), rows[:2], s[:2], ql, tmp_path), golden["A_expected_long_q"])
+    uniq, rows = np.unique(golden["A2_ids"], return_inverse=True)
+    rows = rows.reshape(golden["A2_ids"].shape).astype(np.int64)
+    assert np.array_equal(_ranking_from_rows(uniq.tolist(), rows, golden["A2_scores"], list(range(50)), tmp_path),
+                          golden["A2_expected"])
+
+
+def test_write_ranking_from_rows_edges(tmp_path):
+    rows = np.array([[2, 0, 1]], dtype=np.int64)
+    s = np.array([[0.5, 2.0, 2.0]], dtype=np.float32)
+    p = tmp_path / "r.txt"
+    # multi-byte ids, an empty id, a 1-entry lookup
+    assert drv._write_ranking_from_rows(["é€", "", "日本"], rows, s, ["q"], str(p))
+    assert p.read_text(encoding="utf-8") == "q\té€\t2.0\nq\t\t2.0\nq\t日本\t0.5\n"
+    assert drv._write_ranking_from_rows(["only"], np.zeros((1, 1), np.int64), s[:, :1], ["q"], str(p))
+    assert p.read_text() == "q\tonly\t0.5\n"
+    # out-of-range rows raise what list indexing raises in the reference; ids with a newline go the long way
+    with pytest.raises(IndexError):
+        drv._write_ranking_from_rows(["a", "b"], rows, s, ["q"], str(p))
+    assert drv._write_ranking_from_rows(["a\nb", "c", "d"], rows, s, ["q"], str(p)) is False
+    assert drv._write_ranking_from_rows(["a", "b", "c"], rows.astype(np.int32), s, ["q"], str(p)) is False
+    # the C entry point checks the rows itself
+    ipx = _lib.lib()
+    blob, off = drv._lookup_blob(["a", "b"])
+    qids = np.array(["q"])
+    rc = ipx.ipx_write_ranking_lookup(str(p).encode(), C.c_void_p(qids.ctypes.data), 1, blob, C.c_void_p(off.ctypes.data), 1, 2,
+                                      C.c_void_p(rows.ctypes.data), C.c_void_p(s.ctypes.data), 1, 3)
+    assert rc == 1 and b"out of range" in ipx.ipx_last_error()
+
+
 def test_write_ranking_generic_types_fall_back(tmp_path):
     # float64 scores / list inputs: the Python path, same format as the reference loop
     p = tmp_path / "r.txt"

@@ -143,6 +143,44 @@ def test_cli_under_torchrun_equals_single_process_output(tmp_path, world, nfiles
     assert len((tmp_path / "rank.tsv").read_bytes().splitlines()) == nq * depth
 
 
+def test_one_command_spawns_the_ranks(tmp_path, monkeypatch):
+    """IPX_GPUS=N: the plain CLI command starts N rank processes itself (mural_amd/faiss_retriever/__main__.py::
+    _spawn_ranks) — here 2 ranks over gloo with the oracle engine injected through the rank command — and the
+    ranking file has the bytes of the single-process output. A stray WORLD_SIZE without RANK / MASTER_PORT does
+    not switch the CLI to the distributed path."""
+    import glob
+    import pickle
+    from oracle import oracle as O
+    from mural_amd.faiss_retriever import __main__ as drv
+    d, nq, depth = 24, 9, 7
+    rng = np.random.default_rng(5)
+    for i, n in enumerate([40, 77, 15]):
+        with open(tmp_path / f"corpus_emb{i}.pkl", "wb") as f:
+            pickle.dump((rng.standard_normal((n, d), dtype=np.float32), [f"D{i}_{j}" for j in range(n)]), f)
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    with open(tmp_path / "q.pkl", "wb") as f:
+        pickle.dump((Q, [str(100 + j) for j in range(nq)]), f)
+    argv = ["--query_reps", str(tmp_path / "q.pkl"), "--passage_reps", str(tmp_path / "corpus_emb*.pkl"),
+            "--depth", str(depth), "--batch_size", "4", "--save_ranking_to", str(tmp_path / "rank.tsv"), "--save_text", "--quiet"]
+    for var in ("RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "8")                       # a leftover from some scheduler
+    assert not drv._is_rank_of_a_launch()
+    status = drv._spawn_ranks(argv, 2, entry=[sys.executable, os.path.join(ROOT, "tests", "gloo_rank_main.py")])
+    assert status == 0
+    X, look = [], []
+    for f in glob.glob(str(tmp_path / "corpus_emb*.pkl")):
+        reps, lk = drv.pickle_load(f)
+        X.append(np.asarray(reps, dtype=np.float32))
+        look += lk
+    rD, rI = O.topk_total_order(O.scores_mfma_order(Q, np.concatenate(X)), depth)
+    drv.write_ranking(drv._lookup_strings(look, rI), rD, [str(100 + j) for j in range(nq)], str(tmp_path / "want.tsv"))
+    assert (tmp_path / "rank.tsv").read_bytes() == (tmp_path / "want.tsv").read_bytes()
+    # a rank that fails takes the launch down with its status
+    bad = argv[:3] + [str(tmp_path / "nothing*.pkl")] + argv[4:]
+    assert drv._spawn_ranks(bad, 2, entry=[sys.executable, os.path.join(ROOT, "tests", "gloo_rank_main.py")]) != 0
+
+
 def test_assign_files_contiguous_and_balanced():
     from mural_amd.faiss_retriever.__main__ import _assign_files
     assert _assign_files([10, 10, 10, 10], 2) == [0, 0, 1, 1]
