@@ -13,8 +13,18 @@
  *   - `on_device` != 0 means the data pointers are device (HBM) pointers on the
  *     index's GPU; 0 means host pointers (the library stages the copies itself).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
- *     Calls with host pointers are synchronous; calls with device pointers are
- *     stream-ordered and return without synchronising.
+ *     Calls with host pointers are synchronous. Calls with device pointers are
+ *     stream-ordered; on an index with fp32 rows only (storage 0) they return
+ *     without synchronising. With a bf16 copy (storage 1 or 2) ipx_search /
+ *     ipx_search_aspect / ipx_search_pooled read back one flag word per query
+ *     after the rescoring pass (which queries the margin rule sends to a repeat
+ *     pass) and so synchronise the stream once per pass before they return;
+ *     ipx_merge_topk synchronises when a list exceeds IPX_MAX_K entries.
+ *   - an index serves one call at a time: its scratch buffers, timing events
+ *     and last-search statistics are per index, not per call. Concurrent
+ *     searches need one index per caller (or external locking); different
+ *     indexes on one GPU may run concurrently on different streams (except
+ *     through ipx_search_noalloc, see there).
  *   - doc ids are row numbers in insertion order (faiss IndexFlat semantics) plus
  *     the index's id_base; empty result slots hold id -1 and score -FLT_MAX.
  *   - result order: score descending, ties by ascending id (deterministic;
@@ -43,8 +53,14 @@ enum ipx_status {
 
 enum ipx_dtype { IPX_F32 = 0, IPX_F16 = 1, IPX_BF16 = 2 };
 
-/* Largest k a single search / merge call accepts. */
+/* Depth of ONE pass over the corpus (the longest list the scan and merge kernels hold per query), and the
+ * depth a search / merge CALL accepts: faiss.IndexFlatIP.search takes any k (retriever.py:19, --depth of
+ * __main__.py:58). A call with k > IPX_MAX_K runs ceil(min(k, ntotal) / IPX_MAX_K) fp32 passes, each admitting
+ * only hits after the previous pass's last one in the result order, and returns bit for bit the one sorted list
+ * (the index must keep fp32 rows: storage 0 or 1; bf16-only storage serves k <= IPX_MAX_K * 4 / 5);
+ * ipx_merge_topk does the same over its input lists. ipx_search_noalloc stays single-pass. */
 #define IPX_MAX_K 2048
+#define IPX_MAX_DEPTH (1 << 20)
 
 /* Thread-local message for the last failing call on this thread. */
 const char* ipx_last_error(void);

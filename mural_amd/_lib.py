@@ -19,7 +19,8 @@ SYMBOLS = [
 ]
 
 IPX_F32, IPX_F16, IPX_BF16 = 0, 1, 2
-IPX_MAX_K = 2048
+IPX_MAX_K = 2048            # depth of one pass (include/ipx.h)
+IPX_MAX_DEPTH = 1 << 20     # depth a call accepts
 
 _lib = None
 

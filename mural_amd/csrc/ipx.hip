@@ -120,6 +120,7 @@ struct ipx_index {
     uint16_t* Xh = nullptr;  // packed bf16 corpus (storage 1, 2)
     DevBuf Qp, cand, partD, partI, err, stageIn, stageQ, stageW, outD, outI, trace, pub;
     DevBuf maxsq, qfused, candD, candI, flags, sel, qsel, selD, selI, poolH, poolW, poolQ;
+    DevBuf deepD, deepI, ceilD, ceilI;   // deep searches: one pass's lists, the next pass's ceilings
     void* pinned = nullptr;          // host staging of ipx_add (two slices)
     size_t pinned_bytes = 0;
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
@@ -405,9 +406,11 @@ int scan_f32_small_path(ipx_index* ix, const float* dq, const float* dw, int A, 
 // fp32 scan of nq row-major fp32 queries already on the device (A > 0: aspect embeddings + weights,
 // fused by the pack kernel): pack -> scan -> merge. Results (device) in dD / dI.
 int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
-                  float* dD, int64_t* dI, hipStream_t st, bool primary) {
+                  float* dD, int64_t* dI, hipStream_t st, bool primary, const float* ceilD = nullptr,
+                  const int64_t* ceilI = nullptr) {
     // up to 192 queries: the 32 / 64-query tile does a fraction of the 256-query tile's matrix work
-    if (nq <= ix->small_f32_limit && !ix->no_small_batch)
+    // (passes of a deep search that carry a ceiling stay on the 256-query kernel, the one that knows ceilings)
+    if (nq <= ix->small_f32_limit && !ix->no_small_batch && !ceilI)
         return scan_f32_small_path(ix, dq, dw, A, logits, nq, k, dD, dI, st, primary);
     const bool record = primary && ix->timing;
     const int d = ix->d, nks = ix->nks;
@@ -484,10 +487,13 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
                            (int64_t*)ix->partI.p, nfill);
         IPX_HIP(hipGetLastError());
     }
+    p.ceilD = ceilD;
+    p.ceilI = ceilI;
     const int lds = std::max(2 * ipx::STAGE_BYTES, 4 * cap * 8) + ipx::LDS_STATE_BYTES;
+    void (*kern)(const ipx::ScanParams) = ceilI ? ipx::scan_f32_kernel<true> : ipx::scan_f32_kernel<false>;
     if (lds > 64 * 1024)
-        IPX_HIP(hipFuncSetAttribute((const void*)ipx::scan_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(ipx::scan_f32_kernel, dim3(G), dim3(ipx::NTHREADS), lds, st, p);
+        IPX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3(G), dim3(ipx::NTHREADS), lds, st, p);
     IPX_HIP(hipGetLastError());
     if (record) IPX_HIP(hipEventRecord(ix->ev[2], st));
 
@@ -512,6 +518,38 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
         ix->last_wgs = G;
         ix->last_S = S;
         ix->last_cap = cap;
+    }
+    return 0;
+}
+
+// k beyond IPX_MAX_K (faiss.IndexFlatIP.search takes any k, reference retriever.py:19): one fp32 scan per
+// IPX_MAX_K ranks. Pass j admits only hits strictly after the last hit of pass j-1 in the result order (score
+// descending, row ascending), so its top list is ranks [j * IPX_MAX_K, ...) of the one total order: the
+// concatenation is bit for bit what a single pass of depth k would return. Ranks beyond ntotal are (-FLT_MAX, -1)
+// without a scan. HIP events (ipx_set_timing) cover the first pass.
+int scan_f32_deep(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
+                  float* dD, int64_t* dI, hipStream_t st) {
+    const int64_t k_live = std::min<int64_t>(k, ix->ntotal);
+    if (k_live < k) {
+        const int64_t nout = nq * (int64_t)k;
+        hipLaunchKernelGGL(ipx::fill_empty_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, dD, dI, nout);
+        IPX_HIP(hipGetLastError());
+    }
+    const int step = IPX_MAX_K;
+    if (int rc = ix->deepD.ensure((size_t)nq * step * sizeof(float))) return rc;
+    if (int rc = ix->deepI.ensure((size_t)nq * step * sizeof(int64_t))) return rc;
+    if (int rc = ix->ceilD.ensure((size_t)nq * sizeof(float))) return rc;
+    if (int rc = ix->ceilI.ensure((size_t)nq * sizeof(int64_t))) return rc;
+    for (int64_t off = 0; off < k_live; off += step) {
+        const int kk = (int)std::min<int64_t>(step, k_live - off);
+        if (int rc = scan_f32_path(ix, dq, dw, A, logits, nq, kk, (float*)ix->deepD.p, (int64_t*)ix->deepI.p, st, off == 0,
+                                   off ? (const float*)ix->ceilD.p : nullptr, off ? (const int64_t*)ix->ceilI.p : nullptr))
+            return rc;
+        const int64_t n = nq * (int64_t)kk;
+        hipLaunchKernelGGL(ipx::deep_collect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           (const float*)ix->deepD.p, (const int64_t*)ix->deepI.p, nq, kk, dD, dI, k, (int)off,
+                           (float*)ix->ceilD.p, (int64_t*)ix->ceilI.p);
+        IPX_HIP(hipGetLastError());
     }
     return 0;
 }
@@ -753,7 +791,7 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     // at 2.1k every query was) — so one part as long as 3.2k fits the longest list, its list 5k capped there.
     const int mult1 = ix->storage == 2 ? 2 : 5;
     const bool small = nq <= 64 && !ix->no_small_batch;
-    const bool one_part_fits = ix->storage == 2 ? 2 * k <= 1024 : 16 * k <= 5 * (int)IPX_MAX_K;
+    const bool one_part_fits = ix->storage == 2 ? 2 * k <= 1024 : 11 * k <= 4 * (int)IPX_MAX_K;
     int qparts = ix->query_parts > 0 ? ix->query_parts : ((small || !one_part_fits) ? 2 : 1);
     int kc = ix->force_kc > 0 ? ix->force_kc
              : qparts == 1 ? std::max(256, mult1 * k)
@@ -800,8 +838,8 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
                 float* out_D, int64_t* out_I, int on_device, void* stream) {
     if (!ix) return fail(IPX_ERR_ARG, "search: null index");
     if (nq < 0) return fail(IPX_ERR_ARG, "search: nq < 0");
-    if (k <= 0 || k > IPX_MAX_K)
-        return fail(IPX_ERR_ARG, "search: k=" + std::to_string(k) + " outside [1, " + std::to_string(IPX_MAX_K) + "]");
+    if (k <= 0 || k > IPX_MAX_DEPTH)
+        return fail(IPX_ERR_ARG, "search: k=" + std::to_string(k) + " outside [1, " + std::to_string(IPX_MAX_DEPTH) + "]");
     if (nq == 0) return 0;
     if (!q_src || !out_D || !out_I || (A > 0 && !w)) return fail(IPX_ERR_ARG, "search: null pointer");
     if (nq > (int64_t)0x7fffff00) return fail(IPX_ERR_ARG, "search: nq too large for one call");
@@ -858,7 +896,8 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
         const bool bf16 = ix->storage == 2 ||
                           (ix->storage == 1 && !ix->force_f32_scan && (2 * k <= IPX_MAX_K || ix->force_kc > 0));
         int rc = bf16 ? scan_bf16_path(ix, dq, dw, A, logits, nq, k, dD, dI, st)
-                      : scan_f32_path(ix, dq, dw, A, logits, nq, k, dD, dI, st, true);
+                 : k > IPX_MAX_K ? scan_f32_deep(ix, dq, dw, A, logits, nq, k, dD, dI, st)
+                                 : scan_f32_path(ix, dq, dw, A, logits, nq, k, dD, dI, st, true);
         if (rc) return rc;
     }
 
@@ -870,6 +909,61 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
         IPX_HIP(hipStreamSynchronize(st));
         if (errflag) return fail(IPX_ERR_STATE, "search: candidate queue overflow (internal invariant violated)");
     }
+    return 0;
+}
+
+// Merge with lists or a result beyond IPX_MAX_K entries (device pointers, [S][nq][k_in] -> [nq][k_out]): the input
+// lists are cut into chunks of at most IPX_MAX_K entries and merged by merge_topk_kernel, IPX_MAX_K output ranks per
+// pass; pass j blanks every entry not strictly after the last entry of pass j-1 (deep_stage_kernel), as the scans of a
+// deep search do. Queries go through in batches so the staged copy stays small. Synchronises the stream before it
+// frees its buffers. (An entry present twice with the same score and id is returned once if a pass ends on it.)
+int merge_deep(const float* dD, const int64_t* dI, int S, int64_t nq, int k_in, int k_out, float* oD, int64_t* oI, hipStream_t st) {
+    const int chunk = std::min(k_in, (int)IPX_MAX_K), nchunks = (k_in + chunk - 1) / chunk, step = IPX_MAX_K;
+    const int64_t k_live = std::min<int64_t>(k_out, (int64_t)S * k_in);
+    if (k_live < k_out) {
+        const int64_t nout = nq * (int64_t)k_out;
+        hipLaunchKernelGGL(ipx::fill_empty_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, oD, oI, nout);
+        IPX_HIP(hipGetLastError());
+    }
+    if (k_live == 0) return 0;
+    const int64_t nb_max = std::min<int64_t>(nq, 512);
+    const int64_t Sx = (int64_t)S * nchunks;
+    DevBuf sD, sI, tD, tI, cD, cI;
+    auto cleanup = [&]() { for (DevBuf* b : {&sD, &sI, &tD, &tI, &cD, &cI}) b->release(); };
+    int rc = 0;
+    if ((rc = sD.ensure((size_t)Sx * nb_max * chunk * sizeof(float))) || (rc = sI.ensure((size_t)Sx * nb_max * chunk * sizeof(int64_t))) ||
+        (rc = tD.ensure((size_t)nb_max * step * sizeof(float))) || (rc = tI.ensure((size_t)nb_max * step * sizeof(int64_t))) ||
+        (rc = cD.ensure((size_t)nq * sizeof(float))) || (rc = cI.ensure((size_t)nq * sizeof(int64_t)))) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipSuccess;
+    for (int64_t q0 = 0; q0 < nq && e == hipSuccess; q0 += nb_max) {
+        const int64_t nb = std::min(nb_max, nq - q0);
+        for (int64_t off = 0; off < k_live && e == hipSuccess; off += step) {
+            const int kk = (int)std::min<int64_t>(step, k_live - off);
+            const int64_t nst = Sx * nb * chunk;
+            hipLaunchKernelGGL(ipx::deep_stage_kernel, dim3((unsigned)((nst + 255) / 256)), dim3(256), 0, st, dD, dI, S, nq, k_in,
+                               chunk, nchunks, q0, nb, off ? (const float*)cD.p : nullptr, off ? (const int64_t*)cI.p : nullptr,
+                               (float*)sD.p, (int64_t*)sI.p);
+            const int P = next_pow2(std::max(chunk, kk));
+            const int mlds = P * 24;
+            if (mlds > 64 * 1024)
+                e = hipFuncSetAttribute((const void*)ipx::merge_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mlds);
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nb), dim3(256), mlds, st, (const float*)sD.p,
+                               (const int64_t*)sI.p, (int)Sx, nb, chunk, kk, P, 0, nb * (int64_t)chunk, (int64_t)chunk,
+                               (float*)tD.p, (int64_t*)tI.p, (const int*)nullptr);
+            const int64_t n = nb * (int64_t)kk;
+            hipLaunchKernelGGL(ipx::deep_collect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)tD.p,
+                               (const int64_t*)tI.p, nb, kk, oD + q0 * k_out, oI + q0 * k_out, k_out, (int)off,
+                               (float*)cD.p + q0, (int64_t*)cI.p + q0);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess) return fail(IPX_ERR_HIP, std::string("merge (deep lists): ") + hipGetErrorString(e));
     return 0;
 }
 
@@ -932,7 +1026,7 @@ int ipx_destroy(ipx_index* ix) {
     if (ix->Xp) (void)hipFree(ix->Xp);
     if (ix->Xh) (void)hipFree(ix->Xh);
     for (DevBuf* b : {&ix->Qp, &ix->cand, &ix->partD, &ix->partI, &ix->err, &ix->stageIn, &ix->stageQ, &ix->stageW,
-                      &ix->outD, &ix->outI, &ix->trace, &ix->pub, &ix->maxsq, &ix->qfused, &ix->candD, &ix->candI,
+                      &ix->outD, &ix->outI, &ix->trace, &ix->pub, &ix->maxsq, &ix->qfused, &ix->candD, &ix->candI, &ix->deepD, &ix->deepI, &ix->ceilD, &ix->ceilI,
                       &ix->flags, &ix->sel, &ix->qsel, &ix->selD, &ix->selI, &ix->poolH, &ix->poolW, &ix->poolQ})
         b->release();
     for (auto& e : ix->ev)
@@ -1153,7 +1247,7 @@ int ipx_search_pooled(ipx_index* ix, const float* hidden, int64_t seq_len, const
                       int begin_id, int64_t nq, int k, float* out_D, int64_t* out_I, float* out_att, int on_device,
                       void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (k <= 0 || k > IPX_MAX_K) return fail(IPX_ERR_ARG, "search_pooled: k outside [1, IPX_MAX_K]");
+    if (k <= 0 || k > IPX_MAX_DEPTH) return fail(IPX_ERR_ARG, "search_pooled: k outside [1, IPX_MAX_DEPTH]");
     if (nq > 0 && (!out_D || !out_I)) return fail(IPX_ERR_ARG, "search_pooled: null pointer");
     if (int rc = pool_impl(ix, "search_pooled", hidden, seq_len, W, b, A, begin_id, nq, out_att, on_device, st)) return rc;
     if (nq == 0) return 0;
@@ -1173,8 +1267,8 @@ int ipx_search_pooled(ipx_index* ix, const float* hidden, int64_t seq_len, const
 int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in, int k_out, float* out_D,
                    int64_t* out_I, int on_device, int device, void* stream) {
     if (S < 0 || nq < 0 || k_in <= 0 || k_out <= 0) return fail(IPX_ERR_ARG, "merge: bad sizes");
-    if (k_in > IPX_MAX_K || k_out > IPX_MAX_K)
-        return fail(IPX_ERR_ARG, "merge: k outside [1, " + std::to_string(IPX_MAX_K) + "]");
+    if (k_in > IPX_MAX_DEPTH || k_out > IPX_MAX_DEPTH)
+        return fail(IPX_ERR_ARG, "merge: k outside [1, " + std::to_string(IPX_MAX_DEPTH) + "]");
     if (nq == 0) return 0;
     if ((S > 0 && (!D || !I)) || !out_D || !out_I) return fail(IPX_ERR_ARG, "merge: null pointer");
     if (nq > 0x7fffffffLL) return fail(IPX_ERR_ARG, "merge: nq too large");
@@ -1199,6 +1293,19 @@ int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in
             if (e != hipSuccess) { cleanup(); return fail(IPX_ERR_HIP, std::string("merge H2D: ") + hipGetErrorString(e)); }
         }
         dD = (const float*)bD.p; dI = (const int64_t*)bI.p; oD = (float*)boD.p; oI = (int64_t*)boI.p;
+    }
+    if (k_in > IPX_MAX_K || k_out > IPX_MAX_K) {      // lists beyond what one workgroup sorts in LDS
+        int rc = merge_deep(dD, dI, S, nq, k_in, k_out, oD, oI, st);
+        hipError_t e = hipSuccess;
+        if (!rc && !on_device) {
+            e = hipMemcpyAsync(out_D, oD, nout * sizeof(float), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_I, oI, nout * sizeof(int64_t), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+        if (!on_device) cleanup();
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(IPX_ERR_HIP, std::string("merge: ") + hipGetErrorString(e));
+        return 0;
     }
     const int P = next_pow2(std::max(k_in, k_out));
     const int mlds = P * 24;

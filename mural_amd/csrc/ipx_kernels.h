@@ -197,6 +197,11 @@ struct ScanParams {
     int S_out;           // lists per query in outD / outI (S, or S + helpers in scan_f32_kernel)
     int helpers;         // scan_f32_kernel: list slots per query block for workgroups that finished their own block
     uint32_t* help_ctr;  // [nqb] helper slots handed out (zeroed per search)
+    // Deep searches (k beyond IPX_MAX_K, one pass per IPX_MAX_K ranks; scan_f32_kernel<true> only): query q admits only
+    // hits strictly after (ceilD[q], ceilI[q]) in the result order — the last hit the previous pass returned;
+    // ceilI[q] < 0: that pass ran out of hits, nothing is admitted.
+    const float* ceilD = nullptr;
+    const int64_t* ceilI = nullptr;
     int map = 0;         // bf16 large-batch scans: 0 = logical ids query-block-major (an XCD holds few query blocks x all
                          // splits), 1 = split-major (an XCD holds one or two corpus splits x all query blocks: the
                          // workgroups behind one L2 / the Infinity Cache stream the same corpus tiles)
@@ -401,6 +406,7 @@ __device__ __forceinline__ void issue_stage(const ScanParams& p, char* buf, int6
 // pipeline still issues a copy for it, into a buffer nobody reads, so the loop has no branches).
 struct StageCursor { int t, ks; bool ok; };
 
+template <bool CEIL>
 __global__ void __launch_bounds__(NTHREADS, 2)
 scan_f32_kernel(const ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -663,7 +669,15 @@ scan_f32_kernel(const ScanParams p) {
                         const float sc = acc[i][j][r];
                         if (__any(sc > tau)) {
                             const int64_t doc = docbase + i * 32 + (r & 3) + 8 * (r >> 2);
-                            if (sc > tau && doc < p.N) {
+                            bool admit = sc > tau && doc < p.N;
+                            if constexpr (CEIL) {
+                                if (admit) {        // (padding queries never get here: their tau is +inf)
+                                    const int64_t cid = p.ceilI[(int64_t)qb * BQ + ql];
+                                    admit = cid >= 0 && make_key(sc, (uint32_t)doc) <
+                                                            make_key(p.ceilD[(int64_t)qb * BQ + ql], (uint32_t)(cid - p.id_base));
+                                }
+                            }
+                            if (admit) {
                                 const int pos = lds_atomic_inc_nodma(&cnts[ql]);
                                 if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
                                 else *p.err = 1;
@@ -744,15 +758,68 @@ __global__ void __launch_bounds__(256) fill_empty_kernel(float* D, int64_t* I, i
     if (i < n) { D[i] = -FLT_MAX; I[i] = -1; }
 }
 
+// result order of the merges: score descending (as ordered bits), id ascending
+__device__ __forceinline__ bool entry_before(uint32_t osa, int64_t ida, uint32_t osb, int64_t idb) {
+    return osa > osb || (osa == osb && ida < idb);
+}
+
+// ---- deep lists: k beyond the single-pass limit, IPX_MAX_K ranks per pass -----------------------
+// A pass's lists [nq][kk] go to columns [off, off + kk) of the [nq][k] result, and each query's last hit becomes
+// the next pass's ceiling (id -1: the pass ran out of hits, the next ones return nothing).
+__global__ void __launch_bounds__(256)
+deep_collect_kernel(const float* __restrict__ tD, const int64_t* __restrict__ tI, int64_t nq, int kk, float* __restrict__ D,
+                    int64_t* __restrict__ I, int k, int off, float* __restrict__ ceilD, int64_t* __restrict__ ceilI) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t q = gid / kk;
+    if (q >= nq) return;
+    const int i = (int)(gid - q * kk);
+    const float sc = tD[gid];
+    const int64_t id = tI[gid];
+    D[q * k + off + i] = sc;
+    I[q * k + off + i] = id;
+    if (i == kk - 1) { ceilD[q] = sc; ceilI[q] = id; }
+}
+
+// Stage of a deep merge: S lists of k_in entries per query, any order, cut into chunks of `chunk` entries ->
+// [S * nchunks][nb][chunk] for queries [q0, q0 + nb), entries not strictly after the query's ceiling (and the padding
+// of the last chunk) blanked. ceilI == nullptr: first pass, nothing blanked. The order is merge_topk_kernel's:
+// score descending (-0.0 == +0.0), id ascending.
+__global__ void __launch_bounds__(256)
+deep_stage_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, int S, int64_t nq, int k_in, int chunk,
+                  int nchunks, int64_t q0, int64_t nb, const float* __restrict__ ceilD, const int64_t* __restrict__ ceilI,
+                  float* __restrict__ sD, int64_t* __restrict__ sI) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per_list = nb * chunk;
+    const int64_t l = gid / per_list;                    // staged list: s * nchunks + c
+    if (l >= (int64_t)S * nchunks) return;
+    const int64_t rem = gid - l * per_list;
+    const int64_t qb = rem / chunk;
+    const int i = (int)(rem - qb * chunk);
+    const int s = (int)(l / nchunks), c = (int)(l - (int64_t)s * nchunks);
+    const int e = c * chunk + i;
+    float sc = -FLT_MAX;
+    int64_t id = -1;
+    if (e < k_in) {
+        const int64_t src = ((int64_t)s * nq + q0 + qb) * k_in + e;
+        sc = D[src] + 0.0f;
+        id = I[src];
+        if (ceilI) {
+            const int64_t cid = ceilI[q0 + qb];
+            const float csc = ceilD[q0 + qb] + 0.0f;
+            const bool after = cid >= 0 && sc > -FLT_MAX &&
+                               entry_before(f32_ordered(csc), cid, f32_ordered(sc), id);
+            if (!after) { sc = -FLT_MAX; id = -1; }
+        }
+    }
+    sD[gid] = sc;
+    sI[gid] = id;
+}
+
 // ---- merge: per query, S lists of (score, id) -> global top-k ---------------------------------
 // One workgroup per query keeps the running best P entries sorted in LDS and folds one list
 // at a time into it (the streaming role of faiss ResultHeap.add_result, reducer.py:16):
 //   load list -> [bitonic sort] -> M[i] = better(R[i], L[P-1-i]) -> bitonic merge.
 // Order: score descending, id ascending; scores <= -FLT_MAX and NaN are empty slots.
-
-__device__ __forceinline__ bool entry_before(uint32_t osa, int64_t ida, uint32_t osb, int64_t idb) {
-    return osa > osb || (osa == osb && ida < idb);
-}
 
 __device__ __forceinline__ void wg_cmpx(uint32_t* os, int64_t* id, int lo, int hi, bool desc) {
     const uint32_t a = os[lo], b = os[hi];

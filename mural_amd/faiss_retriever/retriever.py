@@ -104,8 +104,8 @@ class FlatIPIndex:
         n, d = x.shape
         assert d == self.d
         assert k > 0
-        if k > _lib.IPX_MAX_K:
-            raise ValueError(f"k={k} exceeds the engine limit IPX_MAX_K={_lib.IPX_MAX_K}")
+        if k > _lib.IPX_MAX_DEPTH:
+            raise ValueError(f"k={k} exceeds the engine limit IPX_MAX_DEPTH={_lib.IPX_MAX_DEPTH}")
         x = np.ascontiguousarray(x, dtype="float32")
         D = np.empty((n, k), dtype=np.float32)
         I = np.empty((n, k), dtype=np.int64)

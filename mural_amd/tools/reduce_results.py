@@ -56,7 +56,7 @@ def reduce_results(results_dir, output, depth=100, device=None):
     print(f'Writing output to {output} with depth {depth}')
     s32 = sc.astype(np.float32)
     exact = bool(np.all((s32.astype(np.float64) == sc) | np.isnan(sc))) and not np.isnan(sc).any() \
-        and bool(np.all(np.abs(s32) < _FLT_MAX)) and 0 < depth <= _lib.IPX_MAX_K \
+        and bool(np.all(np.abs(s32) < _FLT_MAX)) and 0 < depth <= _lib.IPX_MAX_DEPTH \
         and not bool(np.any((sc == 0) & np.signbit(sc)))      # -0.0 == 0.0 for sorted(), not for the kernel's keys
     if q.size == 0 or not exact:
         with open(output, 'w') as f:

@@ -77,8 +77,10 @@ def test_headline_corpus_8p8m_fp32(R):
     assert torch.equal(Ik[:, :100], I) and torch.equal(Dk[:, :100].contiguous().view(torch.int32), D.view(torch.int32))
     ix.set_param("f32_scan", 0)
     Dk2, Ik2 = ix.search_device(Q, 1000)
-    st = ix.last_bf16_stats()
-    assert st["candidates"] == 2000 and st["fallback_queries"] < nq // 50
+    # (the planted rows have 3x the norm of the others: they set the margin rule's corpus-wide bound, and at this
+    #  depth every query then goes on to the repeat pass / the fp32 scan — the bits must not depend on the route;
+    #  without plants scripts/depth_sweep.py measures 0 repeats at k = 1000)
+    assert ix.last_bf16_stats()["candidates"] == 2000
     assert torch.equal(Ik, Ik2) and torch.equal(Dk.view(torch.int32), Dk2.view(torch.int32))
     del Dk, Ik, Dk2, Ik2
     # (3) small batches on the fp32 rows (scan_f32_small_kernel) and on the bf16 copy: the same bits again,

@@ -165,7 +165,59 @@ def test_dimension_mismatch_and_k_errors(R):
     with pytest.raises(AssertionError):
         r.search(np.zeros((3, 8), np.float32), 0)
     with pytest.raises(ValueError):
-        r.search(np.zeros((3, 8), np.float32), 5000)
+        r.search(np.zeros((3, 8), np.float32), (1 << 20) + 1)       # IPX_MAX_DEPTH
+
+
+# ---- k beyond one pass (IPX_MAX_K = 2048): faiss takes any k (reference retriever.py:19, --depth) ----------
+@pytest.mark.parametrize("n,d,nq,k,storage", [
+    (20000, 64, 37, 5000, "f32"),          # small-batch first pass, then passes under a ceiling
+    (20000, 64, 300, 5000, "f32"),         # two query blocks
+    (20000, 64, 300, 4096, "bf16scan"),    # exactly two full passes; an index that also keeps a bf16 copy
+    (3000, 32, 70, 5000, "f32"),           # k > ntotal: two passes, then padding
+    (2049, 16, 5, 2049, "f32"),            # one rank beyond a pass
+])
+def test_search_deeper_than_one_pass(R, n, d, nq, k, storage):
+    X, Q = gaussian(77, (n, d)), gaussian(78, (nq, d))
+    r = R.BaseFaissIPRetriever(X)
+    r.index = R.FlatIPIndex(d, storage=storage)
+    r.add(X)
+    D, I = r.search(Q, k)
+    assert D.shape == (nq, k) == I.shape
+    assert_bit_exact(D, I, Q, X, k)
+    kk = min(k, n)
+    assert (I[:, kk:] == -1).all() and (D[:, kk:] == -FLT_MAX).all()
+    srt = np.sort(I[:, :kk], axis=1)
+    assert (srt[:, 1:] != srt[:, :-1]).all()                         # no row twice across the pass boundaries
+    # a pass boundary does not show: the single-pass list is the prefix
+    D1, I1 = r.search(Q, 2048)
+    assert np.array_equal(I1, I[:, :2048]) and np.array_equal(D1, D[:, :2048])
+
+
+def test_deep_search_ties_across_the_pass_boundary(R):
+    # 6000 rows, three copies of 2000: every score appears three times, the triples straddle rank 2048 and 4096
+    base = gaussian(5, (2000, 32))
+    X = np.concatenate([base, base, base], axis=0)
+    Q = gaussian(6, (270, 32))
+    r = build(R, X)
+    D, I = r.search(Q, 6000)
+    assert_bit_exact(D, I, Q, X, 6000)
+    assert np.array_equal(D[:, 0::3], D[:, 1::3]) and (I[:, 0::3] < I[:, 1::3]).all() and (I[:, 1::3] < I[:, 2::3]).all()
+    # all-equal scores: rows ascending through every pass
+    Z = np.zeros((5000, 16), np.float32)
+    rz = build(R, Z)
+    Dz, Iz = rz.search(np.ones((3, 16), np.float32), 5000)
+    assert (Dz == 0).all() and (Iz == np.arange(5000)).all()
+
+
+def test_deep_search_skips_nan_rows(R):
+    X = gaussian(7, (5000, 16))
+    X[5, 0] = np.nan
+    X[4000, 1] = np.nan
+    Q = gaussian(8, (9, 16))
+    r = build(R, X)
+    D, I = r.search(Q, 5000)
+    assert_bit_exact(D, I, Q, X, 5000)
+    assert (I[:, -2:] == -1).all() and not (I == 5).any() and not (I == 4000).any()
 
 
 def test_batch_search_equals_one_call_bitwise(R):
@@ -200,7 +252,10 @@ def gpu_merge(Ds, Is, k_out):
 
 @pytest.mark.parametrize("S,nq,k_in,k_out", [(1, 5, 10, 10), (4, 33, 100, 100), (8, 20, 1000, 1000),
                                              (20, 7, 100, 100), (3, 9, 50, 20), (3, 9, 20, 50), (2, 3, 2048, 2048),
-                                             (5, 4, 1, 1)])
+                                             (5, 4, 1, 1),
+                                             # beyond one pass: long lists, long results, both; more queries than a batch
+                                             (3, 9, 5000, 5000), (8, 4, 5000, 100), (4, 6, 1500, 5000), (2, 3, 2049, 6000),
+                                             (2, 700, 2100, 2100)])
 def test_merge_topk_matches_reference(R, S, nq, k_in, k_out):
     rng = np.random.default_rng(S * 1000 + k_in)
     Ds = rng.standard_normal((S, nq, k_in)).astype(np.float32)          # unsorted on purpose
