@@ -9,8 +9,14 @@ with the corpus and the queries already resident in HBM. With N > 1 the corpus i
 over the ranks (strong scaling: the total corpus is fixed), every rank searches all queries on
 its shard, the (score, id) candidates are all-gathered over RCCL and merged on the GPU.
 
+`--workload cfg5` times BASELINE.json configs[4] instead (the default run carries the same measurement as
+`extra.cfg5`): every rank holds a 12.5M x 768 bf16 shard generated on its GPU (weak scaling: 8 ranks = the 100M-row
+corpus), batches of 1..64 queries, each search timed end to end INCLUDING the candidate exchange (one RCCL
+all-gather) and the merge. With one rank the collective runs on a 1-rank NCCL group.
+
 Rank 0 prints ONE JSON line; see DESIGN.md §Measurement for the roofline arithmetic.
 """
+import hashlib
 import argparse
 import json
 import os
@@ -19,6 +25,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# cpu_baseline alternates OpenBLAS sgemm blocks (its own thread pool) with OpenMP heap stages: OpenMP workers that
+# spin between parallel regions take the cores from the sgemm threads (measured 3x slower). Read by libgomp when it
+# loads (with torch), so it is set before any import that brings it in.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: BF16 dense ~2.5 PF
@@ -48,11 +58,91 @@ def cpu_baseline(X_sample, Q, k, n_total):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count()
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or cores
-    return {"value": Q.shape[0] / (dt * scale), "unit": "queries/s", "cores": min(threads, cores), "kind": "port",
+    threads = min(O.num_threads(), cores)                # OpenMP threads of the heap stages (and OpenBLAS's default)
+    return {"value": Q.shape[0] / (dt * scale), "unit": "queries/s", "cores": threads, "kind": "port",
             "sample": f"all {Q.shape[0]} queries x first {X_sample.shape[0]} of {n_total} rows, top-{k}, "
-                      f"{dt:.1f} s measured, scaled x{scale:.1f} in rows; numpy/OpenBLAS sgemm + C heap "
-                      f"(faiss IndexFlatIP restatement; real faiss is not installed on this image)"}
+                      f"{dt:.1f} s measured on {threads} threads (OpenBLAS sgemm blocks + OpenMP heap stages over "
+                      f"queries, as faiss runs them), scaled x{scale:.1f} in rows; faiss IndexFlatIP restatement "
+                      f"(real faiss is not installed on this image)"}
+
+
+def kernel_source_hash():
+    """sha256 of the header the fp32 scan kernel lives in: profiles/latest_scan_f32_pmc.json records the hash of the
+    source it profiled, and its traffic figure is only quoted while the two agree."""
+    with open(os.path.join(ROOT, "mural_amd", "csrc", "ipx_kernels.h"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+CFG5_ROWS_PER_RANK = 12_500_000    # BASELINE.json configs[4]: 100M x 768 bf16 over 8 GPUs
+CFG5_BLOCK = 500_000
+
+
+def run_cfg5(torch, dist, dev, local_rank, rank, world, d, k, rows_per_rank, steps=20, warmup=3):
+    """BASELINE.json configs[4] on this rank's shard: nq in {1..64}, end to end with exchange + merge."""
+    from mural_amd.sharded import ShardedFlatIP
+    lo = rank * rows_per_rank
+    index = ShardedFlatIP(d, row_lo=lo, device=local_rank, storage="bf16")
+    ix = index.engine.index
+    ix.reserve(rows_per_rank)
+    t0 = time.perf_counter()
+    for b in range(0, rows_per_rank, CFG5_BLOCK):
+        g = torch.Generator(device=dev)
+        g.manual_seed(777 + (lo + b) // CFG5_BLOCK)           # counter-based: block id of the global corpus
+        n_b = min(CFG5_BLOCK, rows_per_rank - b)
+        index.add_local(torch.randn((n_b, d), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16))
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    Q = torch.randn((64, d), generator=g, device=dev, dtype=torch.float32)
+    ix.set_timing(True)
+    shard_bytes = rows_per_rank * d * 2
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run(q, exchange):
+        for _ in range(warmup):
+            index.search(q, k, exchange=exchange)
+        barrier()
+        scans = []
+        t = time.perf_counter()
+        for _ in range(steps):
+            index.search(q, k, exchange=exchange)
+            scans.append(ix.last_timing()["scan_ms"])
+        barrier()
+        el = time.perf_counter() - t
+        ix.check()
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el / steps, sum(scans) / len(scans)
+
+    rows = []
+    for bnq in (1, 2, 4, 8, 16, 32, 64):
+        q = Q[:bnq].contiguous()
+        t_local, _ = run(q, False)
+        t_e2e, scan_ms = run(q, True)
+        rows.append({"queries": bnq, "ms_per_search": t_e2e * 1e3, "queries_per_s": bnq / t_e2e,
+                     "local_search_ms": t_local * 1e3, "exchange_merge_us": (t_e2e - t_local) * 1e6,
+                     "scan_ms": scan_ms, "shard_bytes_streamed": shard_bytes,
+                     "roofline": {"bound": "hbm", "achieved": shard_bytes / (scan_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                  "unit": "GB/s", "frac": shard_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                  "kernel": "scan_bf16_kernel<1,2>"},
+                     "end_to_end_hbm_frac": shard_bytes / t_e2e / 1e9 / PEAK_HBM_GBS})
+    del index, ix
+    torch.cuda.empty_cache()
+    return {"what": f"BASELINE.json configs[4]: {world} rank(s) x {rows_per_rank} x {d} bf16 rows generated on the device "
+                    f"(storage bf16), top-{k}, {steps} searches per batch size; ms_per_search is end to end on every rank "
+                    f"(local scan + rescoring, one all-gather of packed (ids, scores) blocks over "
+                    f"{'RCCL' if world > 1 else 'a 1-rank NCCL group'}, GPU merge), max over ranks; "
+                    f"exchange_merge_us = that minus the same search without exchange",
+            "ranks": world, "rows_per_rank": rows_per_rank, "total_rows": world * rows_per_rank,
+            "shard_build_s": round(t_build, 2), "batches": rows}
 
 
 def main():
@@ -73,6 +163,9 @@ def main():
     ap.add_argument("--headline", choices=["f32", "bf16scan"], default="f32",
                     help="which scan the timed K steps use on a bf16scan index (results are bit-identical)")
     ap.add_argument("--no-extras", action="store_true", help="skip the bf16-scan and small-batch measurements")
+    ap.add_argument("--workload", choices=["headline", "cfg5"], default="headline",
+                    help="cfg5: only BASELINE.json configs[4] (12.5M x 768 bf16 shard per rank, batches of 1..64 queries)")
+    ap.add_argument("--cfg5-rows", type=int, default=CFG5_ROWS_PER_RANK, help="rows per rank of the cfg5 shard")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,9 +180,29 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    # (one rank: a 1-rank NCCL group, so the cfg5 measurement runs its all-gather through RCCL)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.workload == "cfg5":
+        res = run_cfg5(torch, dist, dev, local_rank, rank, world, args.dim, args.k, args.cfg5_rows,
+                       steps=max(args.steps, 1), warmup=max(args.warmup, 1))
+        if rank == 0:
+            b64 = res["batches"][-1]
+            print(json.dumps({
+                "metric": "QPS exact top-100 IP search, 100M×768 bf16 corpus row-sharded @8 GPUs, batches of 1..64 queries; % HBM roofline",
+                "value": b64["queries_per_s"], "unit": "queries/s", "n_gpus": world, "steps": max(args.steps, 1),
+                "warmup": max(args.warmup, 1), "ms_per_step": b64["ms_per_search"], "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "bf16 scan + f32 rescoring on bf16 rows",
+                "data": "synthetic: torch.randn -> bf16 on device, corpus seed 777+global block, query seed 4321",
+                "config": {"workload": f"BASELINE.json configs[4]: {world} x {args.cfg5_rows}x{args.dim} bf16 shard(s), "
+                                       f"64-query batches (value), top-{args.k}; all batch sizes in extra.cfg5",
+                           "rows_per_rank": args.cfg5_rows, "dim": args.dim, "k": args.k,
+                           "parallelism": f"row-shard x{world}"},
+                "roofline": b64["roofline"], "cpu_baseline": None, "extra": {"cfg5": res}}), flush=True)
+        dist.destroy_process_group()
+        return
 
     os.environ["IPX_STORAGE"] = args.storage
     n, d, nq, k = args.rows, args.dim, args.queries, args.k
@@ -171,7 +284,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": 2.0 * nq * (hi - lo) * d / (sc2a * 1e-3) / 1e12,
                          "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": 2.0 * nq * (hi - lo) * d / (sc2a * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                         "kernel": "scan_bf16_w16_kernel<1>"}}
+                         "kernel": "scan_bf16_w16_kernel<1, true> (16x16x32 MFMA)"}}
         # the reference's default depth (--depth 1000, src/pretrain_finetune1.sh:218-228): hi + lo query parts
         k_deep = 1000
         old_k = k
@@ -206,26 +319,48 @@ def main():
             el3, sc3, _, _ = timed(Q[:bnq].contiguous(), 20, 3)
             sc3a = sum(sc3) / len(sc3)
             bytes_scan = (hi - lo) * d * 4
+            # the binding roofline: streaming the fp32 rows once, or the fp32 matrix work of the batch — whichever
+            # takes longer at peak (64 queries x 8.8M x 768: 5.5 ms of MFMA > 3.4 ms of HBM)
+            flops = 2.0 * bnq * (hi - lo) * d
+            t_hbm, t_mfma = bytes_scan / (PEAK_HBM_GBS * 1e9), flops / (PEAK_F32_MFMA_TFLOPS * 1e12)
+            if t_mfma > t_hbm:
+                roof = {"bound": "mfma", "achieved": flops / (sc3a * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": t_mfma / (sc3a * 1e-3)}
+            else:
+                roof = {"bound": "hbm", "achieved": bytes_scan / (sc3a * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": t_hbm / (sc3a * 1e-3)}
+            roof["kernel"] = "scan_f32_small_kernel<%d>" % (1 if bnq <= 32 else 2)
+            roof["hbm_time_ms_at_peak"], roof["mfma_time_ms_at_peak"] = t_hbm * 1e3, t_mfma * 1e3
             small32.append({"queries": bnq, "ms_per_search": el3 * 1e3 / 20, "queries_per_s": bnq / (el3 / 20),
-                            "scan_ms": sc3a, "corpus_bytes_streamed": bytes_scan,
-                            "roofline": {"bound": "hbm", "achieved": bytes_scan / (sc3a * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
-                                         "unit": "GB/s", "frac": bytes_scan / (sc3a * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                         "kernel": "scan_f32_small_kernel<%d>" % (1 if bnq <= 32 else 2)}})
+                            "scan_ms": sc3a, "corpus_bytes_streamed": bytes_scan, "roofline": roof})
         ix.set_param("f32_scan", 0)
         extra["small_batch_f32_rows"] = small32
+
+    if not args.no_extras and (n, d) == (8_800_000, 768):
+        # BASELINE.json configs[4] (its own shard per rank, weak scaling), any number of ranks; the headline index goes first
+        del index, ix
+        torch.cuda.empty_cache()
+        extra["cfg5"] = run_cfg5(torch, dist, dev, local_rank, rank, world, d, 100, args.cfg5_rows)
 
     if rank == 0:
         scan_avg = sum(scan_ms) / len(scan_ms)
         flops_launch = 2.0 * nq * (hi - lo) * d                      # algorithmic flops of one scan launch
         achieved = flops_launch / (scan_avg * 1e-3) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if is_bf16 else PEAK_F32_MFMA_TFLOPS
-        traffic = None
+        traffic, traffic_source = None, None
         prof = os.path.join(ROOT, "profiles", "latest_scan_f32_pmc.json")
         if not is_bf16 and (n, nq, world) == (8_800_000, 6980, 1) and os.path.exists(prof):
             # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command
-            # (FETCH_SIZE*1024*2 + WRITE_SIZE*1024, MI355X_MICROARCH.md §HBM); not collectable live
+            # (FETCH_SIZE*1024*2 + WRITE_SIZE*1024, MI355X_MICROARCH.md §HBM); not collectable live. Only quoted
+            # while the kernel's source is the one that was profiled.
             with open(prof) as f:
-                traffic = json.load(f).get("traffic_bytes_per_launch")
+                pj = json.load(f)
+            if pj.get("kernel_source_sha256") == kernel_source_hash():
+                traffic = pj.get("traffic_bytes_per_launch")
+                traffic_source = (f"profiles/latest_scan_f32_pmc.json (rocprofv3 --pmc passes of this command at git "
+                                  f"{pj.get('git_head', '?')}, ipx_kernels.h sha256 {pj['kernel_source_sha256'][:12]}); not measured in this run")
+            else:
+                traffic_source = "none: profiles/latest_scan_f32_pmc.json was taken on an older ipx_kernels.h"
         out = {
             "metric": "QPS exact top-100 IP search, 8.8M×768 corpus @1/8 GPUs; % roofline",
             "value": nq / (ms_per_step * 1e-3),
@@ -242,7 +377,7 @@ def main():
                        "bf16_candidates": bf["candidates"], "repeated_queries": bf["fallback_queries"],
                        "rescore_ms": round(bf["rescore_ms"], 3), "merge_ms": round(tm["merge_ms"], 3)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "scan_bf16_w16_kernel<1>" if is_bf16 else "scan_f32_kernel", "kernel_ms": scan_avg,
                          "flops_per_launch": flops_launch},
         }
@@ -254,8 +389,7 @@ def main():
         if extra:
             out["extra"] = extra
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -152,6 +152,15 @@ int ipx_search_pooled(ipx_index* idx, const float* hidden, int64_t seq_len, cons
 int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in, int k_out,
                    float* out_D, int64_t* out_I, int on_device, int device, void* stream);
 
+/* ipx_merge_topk for the exchange format of the row-sharded search (mural_amd/sharded.py; the reference's
+ * per-shard result pickles + reducer.py:15-18 play this role): every shard's lists for all queries sit in ONE
+ * buffer, so one all-gather moves scores and ids together. Block s of `packed` = int64 ids [nq, k_in] followed
+ * by fp32 scores [nq, k_in]; blocks are ipx_packed_block_bytes(nq, k_in) bytes apart (a multiple of 16).
+ * Device pointers only, stream-ordered, k_in and k_out <= IPX_MAX_K; the result is ipx_merge_topk's. */
+size_t ipx_packed_block_bytes(int64_t nq, int k);
+int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k_out,
+                          float* out_D, int64_t* out_I, int device, void* stream);
+
 /* Index options and tuning knobs. Search RESULTS never depend on any of them, with one
  * documented exception: storage 2 defines the exact score on the bf16-rounded rows.
  *   "storage"    : what the index keeps of the added rows; only while the index is empty.

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libipx.so")
 SYMBOLS = [
     "ipx_last_error", "ipx_version", "ipx_device_count", "ipx_create", "ipx_destroy", "ipx_dim",
     "ipx_ntotal", "ipx_reserve", "ipx_set_id_base", "ipx_add", "ipx_search", "ipx_search_noalloc", "ipx_search_aspect", "ipx_search_pooled", "ipx_pool", "ipx_add_pooled",
-    "ipx_merge_topk", "ipx_set_param", "ipx_read_trace", "ipx_check", "ipx_set_timing", "ipx_last_timing", "ipx_last_geometry",
+    "ipx_merge_topk", "ipx_merge_topk_packed", "ipx_packed_block_bytes", "ipx_set_param", "ipx_read_trace", "ipx_check", "ipx_set_timing", "ipx_last_timing", "ipx_last_geometry",
     "ipx_last_bf16_stats",
     "ipx_write_ranking", "ipx_write_ranking_lookup", "ipx_format_score",
 ]
@@ -67,6 +67,9 @@ def lib():
     L.ipx_pool.argtypes = [vp, f32p, i64, f32p, f32p, i32, i32, i64, f32p, f32p, i32, vp]
     L.ipx_add_pooled.argtypes = [vp, f32p, i64, f32p, f32p, i32, i32, i64, i32, vp]
     L.ipx_merge_topk.argtypes = [f32p, i64p, i32, i64, i32, i32, f32p, i64p, i32, i32, vp]
+    L.ipx_merge_topk_packed.argtypes = [vp, i32, i64, i32, i32, f32p, i64p, i32, vp]
+    L.ipx_packed_block_bytes.argtypes = [i64, i32]
+    L.ipx_packed_block_bytes.restype = C.c_size_t
     L.ipx_set_param.argtypes = [vp, C.c_char_p, i64]
     L.ipx_read_trace.argtypes = [vp, vp, i32]
     L.ipx_check.argtypes = [vp, vp]

@@ -369,7 +369,7 @@ int scan_f32_small_launch(ipx_index* ix, const SmallGeom& g, const SmallBufs& b,
         }
         hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st,
                            (const float*)b.partD, (const int64_t*)b.partI, S, nq, k, k, P, 1,
-                           (int64_t)k, (int64_t)S * k, dD, dI, todo);
+                           (int64_t)k, (int64_t)S * k, dD, dI, todo, (int64_t)0);
         IPX_HIP(hipGetLastError());
         if (record) {
             IPX_HIP(hipEventRecord(ix->ev[3], st));
@@ -506,7 +506,7 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
         // partials are [nq][S][k]: shard stride k, query stride S*k; lists arrive sorted
         hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st,
                            (const float*)ix->partD.p, (const int64_t*)ix->partI.p, S_out, nq, k, k, P, 1,
-                           (int64_t)k, (int64_t)S_out * k, dD, dI, (const int*)nullptr);
+                           (int64_t)k, (int64_t)S_out * k, dD, dI, (const int*)nullptr, (int64_t)0);
         IPX_HIP(hipGetLastError());
         if (record) {
             IPX_HIP(hipEventRecord(ix->ev[3], st));
@@ -694,7 +694,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
         }
         hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st,
                            (const float*)ix->partD.p, (const int64_t*)ix->partI.p, S, nq, kc, kc, P, 1,
-                           (int64_t)kc, (int64_t)S * kc, (float*)ix->candD.p, (int64_t*)ix->candI.p, todo);
+                           (int64_t)kc, (int64_t)S * kc, (float*)ix->candD.p, (int64_t*)ix->candI.p, todo, (int64_t)0);
         IPX_HIP(hipGetLastError());
     }
     if (timing) {
@@ -953,7 +953,7 @@ int merge_deep(const float* dD, const int64_t* dI, int S, int64_t nq, int k_in, 
             if (e != hipSuccess) break;
             hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nb), dim3(256), mlds, st, (const float*)sD.p,
                                (const int64_t*)sI.p, (int)Sx, nb, chunk, kk, P, 0, nb * (int64_t)chunk, (int64_t)chunk,
-                               (float*)tD.p, (int64_t*)tI.p, (const int*)nullptr);
+                               (float*)tD.p, (int64_t*)tI.p, (const int*)nullptr, (int64_t)0);
             const int64_t n = nb * (int64_t)kk;
             hipLaunchKernelGGL(ipx::deep_collect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)tD.p,
                                (const int64_t*)tI.p, nb, kk, oD + q0 * k_out, oI + q0 * k_out, k_out, (int)off,
@@ -1315,7 +1315,7 @@ int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in
     if (e == hipSuccess) {
         // inputs are [S][nq][k_in]: shard stride nq*k_in, query stride k_in; order not assumed
         hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st, dD, dI, S, nq, k_in, k_out,
-                           P, 0, (int64_t)nq * k_in, (int64_t)k_in, oD, oI, (const int*)nullptr);
+                           P, 0, (int64_t)nq * k_in, (int64_t)k_in, oD, oI, (const int*)nullptr, (int64_t)0);
         e = hipGetLastError();
     }
     if (e == hipSuccess && !on_device) {
@@ -1325,6 +1325,35 @@ int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in
     }
     if (!on_device) cleanup();
     if (e != hipSuccess) return fail(IPX_ERR_HIP, std::string("merge: ") + hipGetErrorString(e));
+    return 0;
+}
+
+size_t ipx_packed_block_bytes(int64_t nq, int k) {
+    if (nq < 0 || k <= 0) return 0;
+    return ((size_t)nq * (size_t)k * 12 + 15) / 16 * 16;
+}
+
+int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k_out, float* out_D, int64_t* out_I,
+                          int device, void* stream) {
+    if (S < 0 || nq < 0 || k_in <= 0 || k_out <= 0) return fail(IPX_ERR_ARG, "merge_packed: bad sizes");
+    if (k_in > IPX_MAX_K || k_out > IPX_MAX_K)
+        return fail(IPX_ERR_ARG, "merge_packed: k outside [1, " + std::to_string(IPX_MAX_K) + "] (deeper lists: ipx_merge_topk)");
+    if (nq == 0) return 0;
+    if ((S > 0 && !packed) || !out_D || !out_I) return fail(IPX_ERR_ARG, "merge_packed: null pointer");
+    if (nq > 0x7fffffffLL) return fail(IPX_ERR_ARG, "merge_packed: nq too large");
+    IPX_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t block = ipx_packed_block_bytes(nq, k_in);
+    const int64_t* I = (const int64_t*)packed;
+    const float* D = (const float*)((const char*)packed + (size_t)nq * k_in * sizeof(int64_t));
+    const int P = next_pow2(std::max(k_in, k_out));
+    const int mlds = P * 24;
+    if (mlds > 64 * 1024)
+        IPX_HIP(hipFuncSetAttribute((const void*)ipx::merge_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mlds));
+    hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st, D, I, S, nq, k_in, k_out, P, 0,
+                       (int64_t)(block / sizeof(float)), (int64_t)k_in, out_D, out_I, (const int*)nullptr,
+                       (int64_t)(block / sizeof(int64_t)));
+    IPX_HIP(hipGetLastError());
     return 0;
 }
 

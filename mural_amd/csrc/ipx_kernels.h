@@ -831,9 +831,13 @@ __device__ __forceinline__ void wg_cmpx(uint32_t* os, int64_t* id, int lo, int h
 __global__ void __launch_bounds__(256)
 merge_topk_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, int S, int64_t nq,
                   int k_in, int k_out, int P, int lists_sorted, int64_t shard_stride, int64_t query_stride,
-                  float* __restrict__ outD, int64_t* __restrict__ outI, const int* __restrict__ only_flagged) {
+                  float* __restrict__ outD, int64_t* __restrict__ outI, const int* __restrict__ only_flagged,
+                  int64_t shard_stride_I) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (only_flagged && !only_flagged[blockIdx.x]) return;   // merge_pool_kernel already served this query
+    // lists of one shard packed into one buffer (ipx_merge_topk_packed): ids and scores a different number of
+    // elements apart from shard to shard; 0 = the same stride as the scores
+    if (shard_stride_I == 0) shard_stride_I = shard_stride;
     int64_t* rid = (int64_t*)smem;          // [P]
     int64_t* lid = rid + P;                 // [P]
     uint32_t* ros = (uint32_t*)(lid + P);   // [P]
@@ -846,7 +850,7 @@ merge_topk_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, in
     __syncthreads();
     for (int s = 0; s < S; ++s) {
         const float* d = D + s * shard_stride + q * query_stride;
-        const int64_t* ids = I + s * shard_stride + q * query_stride;
+        const int64_t* ids = I + s * shard_stride_I + q * query_stride;
         for (int i = tid; i < P; i += 256) {
             uint32_t o = 0; int64_t id = INT64_MAX;
             if (i < k_in) {

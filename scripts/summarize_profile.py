@@ -1,5 +1,5 @@
 """Condense a gpurun_out/prof_<tag>/ directory (scripts/profile_bench.sh) into profiles/<name>/."""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, hashlib, json, os, shutil, subprocess, sys
 tag, name = sys.argv[1], sys.argv[2]
 kern = sys.argv[3] if len(sys.argv) > 3 else 'scan_f32'
 src, dst = f'gpurun_out/prof_{tag}', f'profiles/{name}'
@@ -22,5 +22,8 @@ if f is not None and w is not None:
     # the bytes of a wide (16 B/lane, LDS-DMA included) streaming read -> doubled; WRITE_SIZE exact.
     out['traffic_bytes_per_launch'] = f * 1024 * 2 + w * 1024
     out['traffic_note'] = 'memory-side (L2 fabric) bytes: FETCH_SIZE*1024*2 + WRITE_SIZE*1024; Infinity-Cache hits are included'
+# what was profiled: bench.py quotes traffic_bytes_per_launch only while ipx_kernels.h still has this hash
+out['kernel_source_sha256'] = hashlib.sha256(open('mural_amd/csrc/ipx_kernels.h', 'rb').read()).hexdigest()
+out['git_head'] = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
 json.dump(out, open(f'{dst}/{kern}_pmc.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))

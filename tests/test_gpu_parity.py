@@ -402,6 +402,42 @@ def test_device_pointer_api_and_single_rank_sharded(R):
     sh.add_local(torch.from_numpy(X).to(dev))
     sD, sI = sh.search(torch.from_numpy(Q).to(dev), 32)
     assert np.array_equal(sD.cpu().numpy(), D) and np.array_equal(sI.cpu().numpy(), I + 1000)
+    # the exchange forced on one rank (no process group: packed block -> merge; deep lists: per-array path)
+    for k in (32, 2100):
+        eD, eI = sh.search(torch.from_numpy(Q).to(dev), k, exchange=True)
+        pD, pI = sh.search(torch.from_numpy(Q).to(dev), k)
+        assert torch.equal(eD, pD) and torch.equal(eI, pI)
+
+
+def test_merge_packed_equals_merge(R):
+    """ipx_merge_topk_packed reads the shards' (ids, scores) blocks as one all-gather delivers them."""
+    import torch
+    from mural_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(17)
+    for S, nq, k_in, k_out in ((1, 1, 1, 1), (8, 1, 100, 100), (8, 64, 100, 100), (3, 7, 33, 50), (4, 5, 2048, 2048), (2, 9, 7, 3)):
+        Ds = rng.standard_normal((S, nq, k_in)).astype(np.float32)
+        Is = rng.permutation(S * nq * k_in).reshape(S, nq, k_in).astype(np.int64) * 4099 + (1 << 33)
+        Ds[0, 0, :1] = -FLT_MAX
+        Is[0, 0, :1] = -1
+        if k_in > 4:
+            Ds[:, 0, 4] = 0.5                                               # ties across shards
+        block = L.ipx_packed_block_bytes(nq, k_in)
+        assert block % 16 == 0 and block >= nq * k_in * 12
+        buf = np.zeros((S, block), np.uint8)
+        for s in range(S):
+            buf[s, : nq * k_in * 8] = Is[s].reshape(-1).view(np.uint8)
+            buf[s, nq * k_in * 8: nq * k_in * 12] = Ds[s].reshape(-1).view(np.uint8)
+        t = torch.from_numpy(buf).to(dev)
+        oD = torch.empty((nq, k_out), dtype=torch.float32, device=dev)
+        oI = torch.empty((nq, k_out), dtype=torch.int64, device=dev)
+        _lib.check(L.ipx_merge_topk_packed(C.c_void_p(t.data_ptr()), S, nq, k_in, k_out, C.c_void_p(oD.data_ptr()),
+                                           C.c_void_p(oI.data_ptr()), 0, None))
+        torch.cuda.synchronize()
+        rD, rI = O.merge_total_order(Ds, Is, k_out)
+        assert np.array_equal(oI.cpu().numpy(), rI) and np.array_equal(oD.cpu().numpy(), rD), (S, nq, k_in, k_out)
+    assert L.ipx_merge_topk_packed(C.c_void_p(t.data_ptr()), 2, 9, 5000, 3, C.c_void_p(oD.data_ptr()), C.c_void_p(oI.data_ptr()), 0, None) == 1
 
 
 # ---- BASELINE.json configs[1] size: properties that need no CPU reference --------------------

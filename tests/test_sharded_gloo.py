@@ -27,13 +27,35 @@ class OracleEngine:
         x = x.numpy()
         self.X = x if self.X is None else np.concatenate([self.X, x])
 
-    def search(self, q, k):
+    def search(self, q, k, out=None):
         D, I = self.O.topk_total_order(self.O.scores_mfma_order(q.numpy(), self.X), k, id_base=self.base)
-        return torch.from_numpy(D), torch.from_numpy(I)
+        return self._deliver(torch.from_numpy(D), torch.from_numpy(I), out)
+
+    @staticmethod
+    def _deliver(D, I, out):
+        if out is None:
+            return D, I
+        out[0].copy_(D)
+        out[1].copy_(I)
+        return out
 
     def merge(self, D, I, k_out):
         oD, oI = self.O.merge_total_order(D.numpy(), I.numpy(), k_out)
         return torch.from_numpy(oD), torch.from_numpy(oI)
+
+    # the one-collective exchange format (include/ipx.h, ipx_merge_topk_packed), read back on the CPU
+    def out_device(self):
+        return torch.device("cpu")
+
+    def packed_block_bytes(self, nq, k):
+        return (nq * k * 12 + 15) // 16 * 16
+
+    def merge_packed(self, blocks, S, nq, k, k_out):
+        b = blocks.numpy().reshape(S, -1)
+        assert b.shape[1] == self.packed_block_bytes(nq, k)
+        I = np.stack([b[s, : nq * k * 8].copy().view(np.int64).reshape(nq, k) for s in range(S)])
+        D = np.stack([b[s, nq * k * 8: nq * k * 12].copy().view(np.float32).reshape(nq, k) for s in range(S)])
+        return self.merge(torch.from_numpy(D), torch.from_numpy(I), k_out)
 
 
 def _worker(rank, world, port, n, d, nq, k, ret):
@@ -60,7 +82,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("n,k", [(1001, 10), (333, 200)])
+def test_packed_block_size_is_the_librarys():
+    from mural_amd import _lib
+    e = OracleEngine(8)
+    for nq, k in ((1, 1), (1, 100), (3, 7), (64, 100), (6980, 1000)):
+        assert _lib.lib().ipx_packed_block_bytes(nq, k) == e.packed_block_bytes(nq, k)
+
+
+# k <= 2048: one all-gather of packed (ids, scores) blocks; deeper: one all-gather per array
+@pytest.mark.parametrize("n,k", [(1001, 10), (333, 200), (2500, 2100)])
 def test_two_rank_gloo_equals_single_index(n, k):
     from oracle import oracle as O
     d, nq, world = 48, 17, 2
@@ -92,12 +122,13 @@ class NumpyOracleEngine(OracleEngine):
         x = np.asarray(x, dtype=np.float32)
         self.X = x if self.X is None else np.concatenate([self.X, x])
 
-    def search(self, q, k):
+    def search(self, q, k, out=None):
         q = q.numpy() if torch.is_tensor(q) else np.asarray(q, dtype=np.float32)
         if self.X is None:                                   # a rank that owns no shard file
-            return (torch.full((q.shape[0], k), -np.finfo(np.float32).max), torch.full((q.shape[0], k), -1, dtype=torch.int64))
+            return self._deliver(torch.full((q.shape[0], k), -np.finfo(np.float32).max),
+                                 torch.full((q.shape[0], k), -1, dtype=torch.int64), out)
         D, I = self.O.topk_total_order(self.O.scores_mfma_order(q, self.X), k, id_base=self.base)
-        return torch.from_numpy(D), torch.from_numpy(I)
+        return self._deliver(torch.from_numpy(D), torch.from_numpy(I), out)
 
 
 def _cli_worker(rank, world, port, tmp, depth):
