@@ -93,6 +93,9 @@ int ipx_set_id_base(ipx_index* idx, int64_t id_base);
  * Appends n rows of dimension d. `rows` is C-contiguous [n, d] of `dtype`
  * (ipx_dtype); f16/bf16 rows are widened to fp32 on the device, which is what
  * `p_reps.astype('float32')` does on the host in __main__.py:79. */
+/* (A call that fails part-way — a HIP error in the middle of a multi-slice host copy — leaves ntotal and every
+ * search result as they were before the call; the norm bounds of the bf16 margin rule may already include the
+ * rows that were not added, which only makes the rule more cautious.) */
 int ipx_add(ipx_index* idx, const void* rows, int64_t n, int dtype, int on_device, void* stream);
 
 /* Replaces index.search(q_reps, k)                    retriever.py:19
@@ -171,6 +174,10 @@ int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k
  *                  2 bf16 rows only (rows given as bf16 are kept exactly, fp32 / f16 rows are
  *                    rounded to nearest even): bf16 scan, then exact fp32 scores of
  *                    <fp32 query, stored bf16 row>; half the HBM of storage 0; k <= 1638.
+ *                  Queries whose candidate list cannot be proven sufficient (more near-ties than the longest
+ *                  list holds: thousands of duplicate rows, a degenerate embedding) are repeated — storage 1: on
+ *                  the fp32 scan; storage 2: by an exact pass over every stored row, slow but never an error.
+ *                  A zero query needs no repeat (all scores are exactly 0: rows in ascending order).
  *   "bf16_candidates" : candidates per query the bf16 scan keeps (0 = automatic).
  *   "query_parts": bf16 parts per query in the bf16 scan: 1 = bf16(q); 2 = hi + lo (16 bits of
  *                  the query, twice the MFMA work, a far smaller margin); 0 = automatic.
@@ -205,7 +212,7 @@ int ipx_last_timing(ipx_index* idx, float* pack_ms, float* scan_ms, float* merge
 
 /* bf16 scan bookkeeping of the most recent search: time of the rescoring kernel (needs
  * ipx_set_timing), candidates kept per query (0 = the fp32 scan ran), and how many queries
- * failed the sufficiency check and were repeated on the fp32 scan. Any output may be NULL. */
+ * failed the sufficiency check of the first pass and were repeated. Any output may be NULL. */
 int ipx_last_bf16_stats(ipx_index* idx, float* rescore_ms, int* candidates, int64_t* fallback_queries);
 
 /* Launch geometry chosen by the most recent search: workgroups, corpus splits per

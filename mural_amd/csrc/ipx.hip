@@ -706,6 +706,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     rp.candD = (const float*)ix->candD.p;
     rp.candI = (const int64_t*)ix->candI.p;
     rp.q = qf;
+    rp.qmap = nullptr;
     rp.x_is_bf16 = ix->storage == 2;
     rp.X = rp.x_is_bf16 ? (const void*)ix->Xh : (const void*)ix->Xp;
     rp.nks = rp.x_is_bf16 ? ix->nks_h : ix->nks;
@@ -773,8 +774,67 @@ int redo_queries(ipx_index* ix, const float* qf, const std::vector<int>& sel, in
     return 0;
 }
 
+// Last resort of an index without fp32 rows (storage 2): queries whose near-ties outnumber the longest candidate
+// list (thousands of duplicate rows at the top, say) get the exact score of EVERY stored row — the rescoring kernel
+// over lists that enumerate the index, IPX_MAX_K rows per list, then one merge of the lists' top-k. Slow (a full
+// pass of scalar fmaf chains per query: milliseconds per million rows) and exact; one query at a time.
+int exact_rows_path(ipx_index* ix, const float* qf, const std::vector<int>& sel, int k, float* dD, int64_t* dI, hipStream_t st) {
+    const int kc = IPX_MAX_K;
+    const int64_t N = ix->ntotal;
+    const int64_t nlists = (N + kc - 1) / kc, total = nlists * kc;
+    if (nlists > 0x7fffffffLL) return fail(IPX_ERR_ARG, "search: index too large for the exact pass");
+    DevBuf& lD = ix->selD;      // the repeat passes' buffers are free here (their results are already scattered)
+    DevBuf& lI = ix->selI;
+    if (int rc = lD.ensure((size_t)total * sizeof(float))) return rc;
+    if (int rc = lI.ensure((size_t)total * sizeof(int64_t))) return rc;
+    if (int rc = ix->partD.ensure((size_t)nlists * k * sizeof(float))) return rc;
+    if (int rc = ix->partI.ensure((size_t)nlists * k * sizeof(int64_t))) return rc;
+    if (int rc = ix->sel.ensure((size_t)nlists * sizeof(int))) return rc;
+    if (int rc = ix->deepD.ensure((size_t)nlists * sizeof(int))) return rc;      // the lists' (unused) margin flags
+    hipLaunchKernelGGL(ipx::all_rows_lists_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, N, ix->id_base,
+                       total, (float*)lD.p, (int64_t*)lI.p);
+    IPX_HIP(hipGetLastError());
+    ipx::RescoreParams rp;
+    rp.candD = (const float*)lD.p;
+    rp.candI = (const int64_t*)lI.p;
+    rp.q = qf;
+    rp.qmap = (const int*)ix->sel.p;
+    rp.x_is_bf16 = ix->storage == 2;
+    rp.X = rp.x_is_bf16 ? (const void*)ix->Xh : (const void*)ix->Xp;
+    rp.nks = rp.x_is_bf16 ? ix->nks_h : ix->nks;
+    rp.maxsq = (const uint32_t*)ix->maxsq.p;
+    rp.outD = (float*)ix->partD.p;
+    rp.outI = (int64_t*)ix->partI.p;
+    rp.flags = (int*)ix->deepD.p;
+    rp.id_base = ix->id_base;
+    rp.acc_coef = 1.f;
+    rp.qparts = 1;
+    rp.d = ix->d;
+    rp.k = k;
+    rp.kc = kc;
+    rp.P = next_pow2(kc);
+    const int rlds = ((rp.nks * (rp.x_is_bf16 ? 32 : 16) * 4 + 15) & ~15) + rp.P * 8 + 4 * ipx::RS_KB * 16 * ipx::RS_ROW;
+    if (rlds > 64 * 1024)
+        IPX_HIP(hipFuncSetAttribute((const void*)ipx::rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rlds));
+    const int P = next_pow2(k), mlds = P * 24;
+    if (mlds > 64 * 1024)
+        IPX_HIP(hipFuncSetAttribute((const void*)ipx::merge_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mlds));
+    for (int f : sel) {
+        IPX_HIP(hipMemsetD32Async((hipDeviceptr_t)ix->sel.p, f, (size_t)nlists, st));
+        hipLaunchKernelGGL(ipx::rescore_kernel, dim3((unsigned)nlists), dim3(256), rlds, st, rp);
+        IPX_HIP(hipGetLastError());
+        // the lists' top-k (sorted) -> row f of the result
+        hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3(1), dim3(256), mlds, st, (const float*)ix->partD.p,
+                           (const int64_t*)ix->partI.p, (int)nlists, (int64_t)1, k, k, P, 1, (int64_t)k, (int64_t)0,
+                           dD + (size_t)f * k, dI + (size_t)f * k, (const int*)nullptr, (int64_t)0);
+        IPX_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
 // bf16 scan + exact rescoring. Queries that fail the margin check are repeated with the longest
-// candidate list, and whatever still fails goes to the fp32 scan (storage 1 keeps fp32 rows).
+// candidate list, and whatever still fails goes to the fp32 scan (storage 1 keeps fp32 rows) or to the exact pass over
+// the bf16 rows (storage 2).
 int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
                    float* dD, int64_t* dI, hipStream_t st) {
     const int d = ix->d;
@@ -824,10 +884,7 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
         flagged.swap(still);
     }
     if (flagged.empty()) return 0;
-    if (ix->storage != 1)
-        return fail(IPX_ERR_STATE, "search: " + std::to_string(flagged.size()) + " of " + std::to_string(nq) +
-                    " queries have more near-ties than the longest bf16 candidate list holds (" +
-                    std::to_string((int)IPX_MAX_K) + ") and this index keeps no fp32 rows to fall back on; use storage 1");
+    if (ix->storage != 1) return exact_rows_path(ix, qf, flagged, k, dD, dI, st);
     return redo_queries(ix, qf, flagged, k, dD, dI, st, [&](const float* q2, int64_t n2, float* D2, int64_t* I2) {
         return scan_f32_path(ix, q2, nullptr, 0, 0, n2, k, D2, I2, st, false);
     });

@@ -702,6 +702,7 @@ struct RescoreParams {
     const float* candD;      // [nq][kc] approximate scores, descending
     const int64_t* candI;    // [nq][kc] id_base + row, -1 = empty (at the end)
     const float* q;          // [nq][d] fp32 queries, row-major
+    const int* qmap;         // optional: list qi belongs to query qmap[qi] (exact_rows_path: many lists, one query)
     const void* X;           // packed corpus: fp32 (tiles of 128) or bf16 (tiles of 256)
     const uint32_t* maxsq;   // float bits of max_x |x|^2 and max_x |x - bf16(x)|^2
     float* outD;             // [nq][k]
@@ -729,7 +730,7 @@ rescore_kernel(const RescoreParams p) {
     __shared__ int s_m;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t qi = blockIdx.x;
-    const float* q = p.q + qi * (int64_t)p.d;
+    const float* q = p.q + (p.qmap ? (int64_t)p.qmap[qi] : qi) * (int64_t)p.d;
     float ss = 0.f, dd = 0.f;
     for (int e = tid; e < dpad; e += 256) {
         const float v = e < p.d ? q[e] : 0.f;
@@ -757,7 +758,11 @@ rescore_kernel(const RescoreParams p) {
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (cI[mid] >= 0) lo = mid + 1; else hi = mid; }
         const int nvalid = lo;
         int m = nvalid, flag = 0;
-        if (nvalid >= p.kc) {                       // the list is full: it may have cut rows off
+        if (eps == 0.f) {
+            // a zero query (or an all-zero index): every approximate score IS the exact score, the list is in the
+            // result order (score desc, id asc) already — its first k entries are the answer, whatever ties follow
+            m = nvalid < p.k ? nvalid : p.k;
+        } else if (nvalid >= p.kc) {                // the list is full: it may have cut rows off
             const float thr = cD[p.k - 1] - 2.f * eps;   // kc >= k
             if (cD[p.kc - 1] < thr) {
                 lo = p.k; hi = p.kc;                // first index with score < thr
@@ -851,6 +856,15 @@ rescore_kernel(const RescoreParams p) {
         p.outD[qi * p.k + i] = key ? f32_unordered((uint32_t)(key >> 32)) : -FLT_MAX;
         p.outI[qi * p.k + i] = key ? p.id_base + (int64_t)(uint32_t)(~(uint32_t)key) : -1;
     }
+}
+
+// exact_rows_path: candidate lists that enumerate every row of the index, kc rows per list
+__global__ void __launch_bounds__(256)
+all_rows_lists_kernel(int64_t N, int64_t id_base, int64_t total, float* __restrict__ D, int64_t* __restrict__ I) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    D[i] = 0.f;
+    I[i] = i < N ? id_base + i : -1;
 }
 
 // rows sel[i] of src -> row i of dst (queries that go back to the fp32 scan), and the way back

@@ -16,7 +16,10 @@ for lo in range(0, rows, 500000):
     ix.add(x.to(torch.bfloat16) if storage == "bf16" else x)
 del x
 ix.set_timing(True)
-for nq in (1, 4, 16, 32, 64, 65, 128, 256):
+for kv in filter(None, os.environ.get("PARAMS", "").split(",")):      # e.g. PARAMS=query_parts=1,bf16_candidates=256
+    name, val = kv.split("=")
+    ix.set_param(name, int(val))
+for nq in [int(x) for x in os.environ.get("NQ", "1,4,16,32,64,65,128,256").split(",")]:
     Q = torch.randn((nq, d), generator=g, device=dev)
     for _ in range(2):
         ix.search_device(Q, k)

@@ -112,15 +112,35 @@ def test_short_candidate_lists_are_caught_and_repeated(R):
     D, I = ix.search(Q, k)
     assert_bits(D, I, Q, X, k)
     assert ix.last_bf16_stats()["fallback_queries"] == nq
-    # bf16-only storage has nothing exact to fall back on: the longest list is tried, then a clear error
+    # bf16-only storage: the longest list is tried, then the exact pass over every stored row
     ix2 = index(R, X, "bf16")
     ix2.set_param("bf16_candidates", 16)
-    from mural_amd._lib import IpxError
-    try:
-        D2, I2 = ix2.search(Q, k)
-        assert_bits(D2, I2, Q, bf16_round(X), k)      # the 2048-long retry was enough
-    except IpxError as e:
-        assert e.code == 4 and "near-ties" in str(e)
+    D2, I2 = ix2.search(Q, k)
+    assert_bits(D2, I2, Q, bf16_round(X), k)
+
+
+def test_zero_query_and_mass_ties_do_not_fail_the_batch(R):
+    """A zero embedding (every score 0: as many exact ties as rows) and thousands of duplicate rows at the top of
+    a ranking, next to ordinary queries in one batch — every storage returns the one total order (score desc, row
+    asc), the same bits as the fp32 scan."""
+    rng = np.random.default_rng(9)
+    d, n, k = 64, 9000, 50
+    X = gaussian(31, (n, d))
+    dup = gaussian(32, (1, d))
+    X[2000:5000] = dup                                   # 3000 identical rows: more than the longest candidate list
+    Q = gaussian(33, (70, d))
+    Q[3] = 0.0                                           # the zero query
+    Q[7] = dup[0] * 2.0                                  # the duplicates are its best hits, all tied
+    Q[64] = 0.0
+    for storage, ref in (("f32", X), ("bf16scan", X), ("bf16", bf16_round(X))):
+        ix = index(R, X, storage)
+        for nq in (70, 8):                               # large-batch and small-batch kernels
+            D, I = ix.search(Q[:nq], k)
+            assert_bits(D, I, Q[:nq], ref, k)
+            assert (D[3] == 0).all() and (I[3] == np.arange(k)).all()
+            assert (I[7] == 2000 + np.arange(k)).all()
+        D, I = ix.search(Q[:8], 1500)                    # deep list on tie masses
+        assert_bits(D, I, Q[:8], ref, 1500)
 
 
 def test_bf16_edge_cases(R):
