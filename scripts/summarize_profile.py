@@ -25,5 +25,8 @@ if f is not None and w is not None:
 # what was profiled: bench.py quotes traffic_bytes_per_launch only while ipx_kernels.h still has this hash
 out['kernel_source_sha256'] = hashlib.sha256(open('mural_amd/csrc/ipx_kernels.h', 'rb').read()).hexdigest()
 out['git_head'] = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
-json.dump(out, open(f'{dst}/{kern}_pmc.json', 'w'), indent=1)
+import re
+safe = re.sub(r'[^A-Za-z0-9]+', '_', kern).strip('_')      # scan_bf16_kernel<1, 2> -> scan_bf16_kernel_1_2
+out['kernel'] = kern
+json.dump(out, open(f'{dst}/{safe}_pmc.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
