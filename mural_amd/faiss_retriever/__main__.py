@@ -121,9 +121,20 @@ def _lookup_blob(p_lookup):
     return joined, off
 
 
-def _write_ranking_from_rows(p_lookup, all_indices, all_scores, q_lookup, ranking_save_file):
+def _lookup_blob_async(p_lookup):
+    """_lookup_blob on a worker thread: the id table only depends on the shards' lookup lists, so it is put together
+    while the GPU searches (the search waits inside the library with the GIL released). Returns a future."""
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ipx-lookup")
+    fut = pool.submit(_lookup_blob, p_lookup)
+    pool.shutdown(wait=False)
+    return fut
+
+
+def _write_ranking_from_rows(p_lookup, all_indices, all_scores, q_lookup, ranking_save_file, table=None):
     """search_queries' id mapping + write_ranking in one pass (text output of the CLI): the ranking file straight
     from the row ids the search returned, byte for byte what write_ranking(_lookup_strings(...), ...) writes.
+    `table`: a future from _lookup_blob_async(p_lookup), if the caller started one.
     Returns False when the inputs are not of the kind the C writer takes (the caller then goes the long way)."""
     scores, rows = np.asarray(all_scores), np.asarray(all_indices)
     n = len(p_lookup)
@@ -134,7 +145,7 @@ def _write_ranking_from_rows(p_lookup, all_indices, all_scores, q_lookup, rankin
         raise IndexError("list index out of range")
     nq = min(len(q_lookup), scores.shape[0])
     qids = np.array([str(q) for q in q_lookup[:nq]]) if nq else np.array([], dtype="<U1")
-    table = _lookup_blob(p_lookup)
+    table = table.result() if table is not None else _lookup_blob(p_lookup)
     if qids.dtype.kind != "U" or table is None:
         return False
     blob, off = table
@@ -318,6 +329,7 @@ def _main_sharded(args, engine_factory=None):
 
         q_reps, q_lookup = pickle_load(args.query_reps)
         q_reps = q_reps.astype('float32')
+        table = _lookup_blob_async(look_up) if rank == 0 and args.save_text and look_up else None
         logger.info('Index Search Start')
         # chunking never changes a result here (a score does not depend on its batch): large chunks
         chunk = q_reps.shape[0] if args.batch_size <= 0 else max(args.batch_size, 8192)
@@ -333,7 +345,7 @@ def _main_sharded(args, engine_factory=None):
             all_scores = np.concatenate(all_scores) if all_scores else np.empty((0, k), np.float32)
             all_indices = np.concatenate(all_indices) if all_indices else np.empty((0, k), np.int64)
             if args.save_text:
-                if not _write_ranking_from_rows(look_up, all_indices, all_scores, q_lookup, args.save_ranking_to):
+                if not _write_ranking_from_rows(look_up, all_indices, all_scores, q_lookup, args.save_ranking_to, table):
                     write_ranking(_lookup_strings(look_up, all_indices), all_scores, q_lookup, args.save_ranking_to)
             else:
                 pickle_save((all_scores, _lookup_strings(look_up, all_indices)), args.save_ranking_to)
@@ -403,14 +415,16 @@ def main(argv=None):
 
     logger.info('Index Search Start')
     if args.save_text:
-        # text output: the row ids go straight to the writer together with the lookup table; the [nq, depth]
-        # array of id strings that search_queries builds is only needed for the pickle output
+        # text output: the row ids go straight to the writer together with the lookup table (put together while the
+        # GPU searches); the [nq, depth] array of id strings that search_queries builds is only needed for the
+        # pickle output
+        table = _lookup_blob_async(look_up) if look_up else None
         if args.batch_size > 0:
             all_scores, all_indices = retriever.batch_search(q_reps, args.depth, args.batch_size, args.quiet)
         else:
             all_scores, all_indices = retriever.search(q_reps, args.depth)
         logger.info('Index Search Finished')
-        if not _write_ranking_from_rows(look_up, all_indices, all_scores, q_lookup, args.save_ranking_to):
+        if not _write_ranking_from_rows(look_up, all_indices, all_scores, q_lookup, args.save_ranking_to, table):
             write_ranking(_lookup_strings(look_up, all_indices), all_scores, q_lookup, args.save_ranking_to)
         return
     all_scores, psg_indices = search_queries(retriever, q_reps, look_up, args)

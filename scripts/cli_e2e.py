@@ -28,10 +28,16 @@ args = argparse.Namespace(batch_size=128, depth=depth, quiet=True)
 t = [time.perf_counter()]
 retriever, look_up = drv._load_index(f"{tmp}/corpus_emb*.pkl"); t.append(time.perf_counter())
 q_reps, q_lookup = drv.pickle_load(f"{tmp}/q.pkl"); q_reps = q_reps.astype('float32'); t.append(time.perf_counter())
+table = drv._lookup_blob_async(look_up)          # as main() does: the id table is put together while the GPU searches
 all_scores, all_indices = retriever.batch_search(q_reps, args.depth, args.batch_size, args.quiet); t.append(time.perf_counter())
+# --save_text: row ids + lookup table straight to the C writer (ipx_write_ranking_lookup)
+assert drv._write_ranking_from_rows(look_up, all_indices, all_scores, q_lookup, f"{tmp}/rank.tsv", table); t.append(time.perf_counter())
+# the pickle-output route, for comparison: the [nq, depth] array of id strings, then ipx_write_ranking
 psg = drv._lookup_strings(look_up, all_indices); t.append(time.perf_counter())
-drv.write_ranking(psg, all_scores, q_lookup, f"{tmp}/rank.tsv"); t.append(time.perf_counter())
-names = ["load index (unpickle + ipx_add)", "load queries", "batch_search", "row ids -> doc id strings", "write_ranking"]
+drv.write_ranking(psg, all_scores, q_lookup, f"{tmp}/rank2.tsv"); t.append(time.perf_counter())
+assert open(f"{tmp}/rank.tsv", "rb").read() == open(f"{tmp}/rank2.tsv", "rb").read()
+names = ["load index (unpickle + ipx_add)", "load queries", "batch_search", "text output: rows -> ranking file",
+         "(old route) row ids -> doc id strings", "(old route) write_ranking"]
 gb = nshards * rows_per_shard * d * 4 / 1e9
 for n, a, b in zip(names, t, t[1:]):
     print(f"{n:34s} {b-a:7.2f} s")
