@@ -190,8 +190,11 @@ int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k
  *                  one query part, 8 with two; results do not depend on it).
  *   "bf16_shape16" : the 16-wave bf16 scan uses v_mfma_f32_16x16x32_bf16 (1, default: measured 2-4 % faster
  *                  on the 8.8M x 768 workload) or v_mfma_f32_32x32x16_bf16 (0).
+ *   "bf16_ring"  : LDS stage-ring depth of the 16-wave bf16 scan: 2 (default: one stage in flight — measured 10 %
+ *                  faster than 4 on the 8.8M x 768 workload, half the L2 fetch traffic), 3 or 4.
+ *   "bf16_occ"   : with the 2-deep ring, workgroups per CU of that kernel (1 default; 2 measured slower).
  *   "bf16_variant", "bf16_map", "bf16_pp" : measurement aids of the large-batch bf16 scan (issue order behind the
- *                  stage barrier + non-temporal corpus pieces; workgroup -> (query block, split) mapping;
+ *                  stage barrier + non-temporal corpus pieces; query blocks per group of the workgroup -> (query block, split) mapping;
  *                  1 / 2 = ping-pong kernel, 3 / 4 = direct-corpus-operand kernel, see csrc/ipx_bf16_*_kernels.h).
  *   "run_tiles"  : fp32 large-tile scan: corpus tiles per run of the dynamic split (0 = automatic).
  *   "trace"      : 1 = every scan workgroup records {start, end (100 MHz ticks), HW_ID,

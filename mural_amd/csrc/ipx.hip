@@ -140,6 +140,8 @@ struct ipx_index {
     int run_tiles = 0;             // fp32 large-tile scan: corpus tiles per run of the dynamic split (0 = automatic)
     int bf16_pp = 0;               // large-batch bf16 scan, one query part: 1 / 2 = ping-pong kernel (2: with s_setprio)
     int bf16_map = 0;              // large-batch bf16 scan: ScanParams::map
+    int bf16_ring = 2;             // 16-wave bf16 scan, one query part: stage-ring depth (2 = default, 3, 4)
+    int bf16_occ = 1;              // ... workgroups per CU with the 2-deep ring (1, 2)
     int bf16_variant = 0;          // 16-wave bf16 scan, one query part: issue order behind the barrier (0..3) + 4 * non-temporal corpus pieces
     int bf16_waves = 0;            // large-batch bf16 scan: 8 (scan_bf16_kernel<4>) or 16 waves (scan_bf16_w16_kernel); 0 = automatic
     bool no_small_batch = false;   // diagnostic: always use the 256-query bf16 scan variant
@@ -578,7 +580,18 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     const int stage_b = bq * 64 * qparts;
     const int nqb = (int)((nq + bq - 1) / bq);
     const int ntiles = (int)((N + ipx::HBD - 1) / ipx::HBD);
-    const int resident = ix->num_cus;                       // one 512-thread workgroup per CU
+    // large batches, one query part: the 16-wave kernel, whose ring depth (and with a 64-KiB ring its workgroups per
+    // CU) can be chosen
+    const bool w16_1 = !small && ix->bf16_pp == 0 &&
+                       ((qparts == 1 && (ix->bf16_waves == 16 || ix->bf16_waves == 0) && ix->bf16_shape16) ||
+                        (qparts == 2 && ix->bf16_waves == 16));
+    // Ring depth. Two stages (one in flight) measured fastest on the 8.8M x 768 x 6980-query workload: 84 ms against
+    // 93 ms with four — the workgroups that stream the same corpus split then keep each other in step through L2
+    // (a workgroup that runs ahead misses L2 and waits on HBM, its followers hit), L2 fetch traffic per launch
+    // halves (396 -> 170-190 GB) and the chip holds 2.06 instead of 1.82 GHz.
+    const int w16_ring = w16_1 && ix->bf16_ring != 4 ? ix->bf16_ring : 0;   // 0 = the four-deep ring of WCfg
+    const int occ = (w16_ring == 2 && qparts == 1 && ix->bf16_occ == 2) ? 2 : 1;
+    const int resident = occ * ix->num_cus;                 // one workgroup per CU (two with the 64-KiB ring, if asked)
     int S = std::max(1, resident / nqb);
     if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
     int R = 4;                                               // tiles per run: a power of two in [4, 64]
@@ -589,8 +602,15 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     // queue: kc survivors of a compaction + 2 tiles of appends before the next one runs + room to fill
     const int cap = next_pow2(kc + 2 * ipx::HBD + kc / 2);
     const int ring = small ? (qparts == 2 ? ipx::HCfg<1, 2>::RING : ipx::HCfg<1, 1>::RING)
+                     : w16_ring == 2 ? (qparts == 2 ? ipx::WCfg<2, 2>::RING : ipx::WCfg<1, 2>::RING)
+                     : (w16_ring == 3 && qparts == 1) ? ipx::WCfg<1, 3>::RING
                            : (qparts == 2 ? ipx::HCfg<4, 2>::RING : ipx::HCfg<4, 1>::RING);
-    const int nsortwaves = std::max(1, std::min(8, ring / (cap * 8)));
+    // LDS for the episodes: the stage ring's bytes, or for the 16-wave kernel (one workgroup per CU, so the CU's LDS
+    // is its own) at least 128 KiB whatever the ring depth
+    const bool w16k = !small && (ix->bf16_waves == 16 || (ix->bf16_waves == 0 && qparts == 1)) && ix->bf16_pp == 0;
+    const int sort_bytes = w16k && occ == 1 ? std::max(ring, 128 * 1024) : ring;
+    const int nsortwaves = std::max(1, std::min(8, sort_bytes / (cap * 8)));
+    const int nselect = w16k ? std::max(1, std::min(16, sort_bytes / (cap * 4))) : 0;
 
     if (int rc = ix->Qp.ensure((size_t)nqb * nks * stage_b)) return rc;
     if (int rc = ix->cand.ensure((size_t)G * bq * cap * sizeof(uint64_t))) return rc;
@@ -645,8 +665,9 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     p.helpers = 0;
     p.help_ctr = nullptr;
     p.ntiles = ntiles;
-    p.map = small ? 0 : ix->bf16_map;
-    const int lds = std::max(ring, nsortwaves * cap * 8) + ipx::LDS_STATE_BYTES;
+    p.map = small ? 0 : ix->bf16_map == 1 ? nqb : ix->bf16_map;      // 1 = one group of all query blocks
+    p.nselect = nselect;
+    const int lds = std::max({ring, nsortwaves * cap * 8, nselect * cap * 4}) + ipx::LDS_STATE_BYTES;
     {
         // one query part: the 16-wave variant is 9 % faster (8.8M x 768, 6980 queries: 93 vs 102 ms);
         // hi + lo parts: no difference, the 8-wave kernel stays
@@ -668,6 +689,8 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
                 default: break;
             }
         }
+        if (w16 && w16_ring == 2) kern = qparts == 2 ? ipx::scan_bf16_w16_kernel<2, false, 0, false, 2> : ipx::scan_bf16_w16_kernel<1, true, 0, false, 2>;
+        if (w16 && w16_ring == 3 && qparts == 1) kern = ipx::scan_bf16_w16_kernel<1, true, 0, false, 3>;
         if (pp) kern = ix->bf16_pp == 2 ? ipx::scan_bf16_pp_kernel<true> : ipx::scan_bf16_pp_kernel<false>;
         if (dx) kern = ix->bf16_pp == 4 ? ipx::scan_bf16_dx_kernel<true> : ipx::scan_bf16_dx_kernel<false>;
         IPX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1449,7 +1472,18 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
         return 0;
     }
     if (!strcmp(name, "bf16_map")) {
-        ix->bf16_map = value != 0;
+        if (value < 0 || value > 4096) return fail(IPX_ERR_ARG, "set_param: bf16_map outside [0, 4096]");
+        ix->bf16_map = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "bf16_ring")) {
+        if (value != 0 && (value < 2 || value > 4)) return fail(IPX_ERR_ARG, "set_param: bf16_ring is 0 (default), 2, 3 or 4");
+        ix->bf16_ring = value == 0 ? 2 : (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "bf16_occ")) {
+        if (value < 1 || value > 2) return fail(IPX_ERR_ARG, "set_param: bf16_occ is 1 or 2");
+        ix->bf16_occ = (int)value;
         return 0;
     }
     if (!strcmp(name, "bf16_variant")) {

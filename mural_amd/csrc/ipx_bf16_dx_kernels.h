@@ -100,7 +100,8 @@ scan_bf16_dx_kernel(const ScanParams p, const int nsortwaves) {
     const int r15 = lane & 15, g4 = lane >> 4;
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int qb = logical / p.S, split = logical - qb * p.S;
+    int qb, split;
+    decode_block(p.map, p.S, (int)gridDim.x / p.S, logical, qb, split);
 
     if (tid < BQ_) {
         cnts[tid] = 0;

@@ -69,8 +69,8 @@ scan_bf16_pp_kernel(const ScanParams p, const int nsortwaves) {
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int nqb_ = (int)gridDim.x / p.S;
-    const int qb = p.map ? logical % nqb_ : logical / p.S;
-    const int split = p.map ? logical / nqb_ : logical - qb * p.S;
+    int qb, split;
+    decode_block(p.map, p.S, nqb_, logical, qb, split);
 
     if (tid < BQ_) {
         cnts[tid] = 0;

@@ -10,11 +10,11 @@
 
 namespace ipx {
 
-template <int QP> struct WCfg {
+template <int QP, int NB = 0> struct WCfg {
     static constexpr int THREADS = 1024;
     static constexpr int PART_B = 256 * 64;                  // one part of the query stage: 16 KiB
     static constexpr int STAGE = HSTAGE_A + PART_B * QP;     // 32 / 48 KiB
-    static constexpr int NBUF = QP == 1 ? 4 : 3;             // ring: 128 / 144 KiB
+    static constexpr int NBUF = NB ? NB : (QP == 1 ? 4 : 3); // ring: 128 / 144 KiB unless a shallower one is asked for
     static constexpr int LOADS = 1 + QP;                     // copy pieces per wave per stage
     static constexpr int RING = NBUF * STAGE;
 };
@@ -56,16 +56,20 @@ __device__ __forceinline__ void w16_wait2(f32x4& b0, f32x4& b1) {
 // ORD: issue order behind the per-stage barrier: 0 = copy pieces, then the four MFMAs; 1 = MFMAs, then pieces;
 //      2 = two MFMAs, corpus piece, two MFMAs, query piece(s); 3 = as 1 with s_setprio 1 around the MFMAs.
 // NT : corpus pieces carry the non-temporal hint (they do not displace the query blocks from L2).
-template <int QP, bool S16, int ORD = 0, bool NT = false>
+// NB : stage-ring depth (0 = the default of WCfg).
+template <int QP, bool S16, int ORD = 0, bool NT = false, int NB = 0>
 __global__ void __launch_bounds__(1024)
 scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
     static_assert(!S16 || QP == 1, "the 16x16x32 variant exists for one query part");
     static_assert(!S16 || ORD == 0, "issue-order variants exist for the 32x32x16 form");
-    using C = WCfg<QP>;
+    using C = WCfg<QP, NB>;
     constexpr int BQ_ = 256, NBUF = C::NBUF, STAGE = C::STAGE, LOADS = C::LOADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int scratch_bytes = nsortwaves * p.cap * 8;
-    const int stage_region = scratch_bytes > C::RING ? scratch_bytes : C::RING;
+    // the state words sit behind whichever is largest: the ring, the final sorts' scratch, the selections' scratch
+    // (the host sizes the allocation by the same rule)
+    int stage_region = C::RING;
+    if (nsortwaves * p.cap * 8 > stage_region) stage_region = nsortwaves * p.cap * 8;
+    if (p.nselect * p.cap * 4 > stage_region) stage_region = p.nselect * p.cap * 4;
     int* cnts = (int*)(smem + stage_region);
     float* taus = (float*)(smem + stage_region + BQ_ * 4);
     int* flags = (int*)(smem + stage_region + 2 * BQ_ * 4);
@@ -77,8 +81,8 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int nqb_ = (int)gridDim.x / p.S;
-    const int qb = p.map ? logical % nqb_ : logical / p.S;
-    const int split = p.map ? logical / nqb_ : logical - qb * p.S;
+    int qb, split;
+    decode_block(p.map, p.S, nqb_, logical, qb, split);
 
     if (tid < BQ_) {
         cnts[tid] = 0;
@@ -90,6 +94,7 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
 
     uint64_t* myqueues = p.cand + (size_t)blockIdx.x * BQ_ * p.cap;
     uint64_t* scratch = (uint64_t*)smem + (size_t)wave * p.cap;
+    const int nselect = p.nselect > 0 ? p.nselect : nsortwaves;
 
     const int sw = (lane >> 2) & 3;
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -128,6 +133,11 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
 
     int slot = 0, tiles_done = 0;
     f32x4 a0, a1, b0, b1, c0, c1;
+    // optional trace (ipx_set_param "trace"), the record layout of scan_bf16_kernel: wave 0's cycles in the filter and
+    // in episodes, appends of all lanes, episodes
+    uint64_t tr_begin = 0, tr_epi = 0, tr_sort = 0, tr_e0 = 0, tr_e1 = 0;
+    uint32_t tr_appends = 0, tr_episodes = 0;
+    if (p.trace) tr_begin = __builtin_readcyclecounter();
     while (w0.ok) {
         const int t = w0.t;
         bool episode;
@@ -205,6 +215,7 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
 
             // ---- epilogue: threshold filter, rare append to the per-query queues ----
             ++tiles_done;
+            if (p.trace) tr_e0 = __builtin_readcyclecounter();
             const int docbase = t * HBD + wd * 64 + 4 * h;
             episode = lds_read_i32_nodma(&flags[(tiles_done + 1) & 1]) != 0;
             int* myflag = &flags[tiles_done & 1];
@@ -231,6 +242,7 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
                                     if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
                                     else *p.err = 1;
                                     if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
+                                    ++tr_appends;
                                 }
                             }
                         }
@@ -283,6 +295,7 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
             }
 #undef IPX_W16_ROW
             ++tiles_done;
+            if (p.trace) tr_e0 = __builtin_readcyclecounter();
             const int docbase = t * HBD + wd * 64 + 4 * g4;
             episode = lds_read_i32_nodma(&flags[(tiles_done + 1) & 1]) != 0;
             int* myflag = &flags[tiles_done & 1];
@@ -296,6 +309,9 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[i][j][r]);
                 if (__any(m > tau)) {
+                    // (Counting a lane's hits and taking all its queue slots with one LDS atomic, then a predicated
+                    // store per register, was measured: 89.5 against 84 ms — in the steady state a group has 0 or 1
+                    // hit, and sixteen exec-masked store blocks cost more than sixteen wave-uniform branches.)
                     uint64_t* qu = myqueues + (size_t)ql * p.cap;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -309,22 +325,25 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
                                     if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
                                     else *p.err = 1;
                                     if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
+                                    ++tr_appends;
                                 }
                             }
                         }
                 }
             }
         }
+        if (p.trace) { tr_e1 = __builtin_readcyclecounter(); tr_epi += tr_e1 - tr_e0; }
         episode = episode || is_pow4(tiles_done);
         if (episode) {
+            ++tr_episodes;
             // the selection scratch aliases the stage ring: let every copy land, compact, fetch the NBUF stages again
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid < 2) flags[tid] = 0;
-            if (wave < nsortwaves)
-                for (int ql = wave; ql < BQ_; ql += nsortwaves)
-                    compact_query_select(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
-                                         mypub ? mypub + ql : nullptr);
+            if (wave < nselect)
+                for (int ql = wave; ql < BQ_; ql += nselect)
+                    compact_query_select(p, (uint64_t*)((uint32_t*)smem + (size_t)wave * p.cap), cnts, taus,
+                                         myqueues + (size_t)ql * p.cap, ql, lane, mypub ? mypub + ql : nullptr);
             __syncthreads();
             if (tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
             Walker wr = w0;
@@ -336,8 +355,21 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
             }
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 1)) : "memory");
             __syncthreads();
+            if (p.trace) tr_sort += __builtin_readcyclecounter() - tr_e1;
         } else if ((tiles_done & 1) == 0 && is_pow4(tiles_done >> 1)) {
             if (tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
+        }
+    }
+    if (p.trace) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tr_appends += __shfl_xor(tr_appends, off);
+        if (lane == 0) atomicAdd((unsigned long long*)(p.trace + (size_t)blockIdx.x * 4 + 3), ((unsigned long long)tr_appends << 16));
+        if (tid == 0) {
+            uint64_t* tr = p.trace + (size_t)blockIdx.x * 4;
+            tr[0] = __builtin_readcyclecounter() - tr_begin;
+            tr[1] = tr_epi;
+            tr[2] = tr_sort;
+            atomicAdd((unsigned long long*)(tr + 3), (unsigned long long)tr_episodes);
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -76,7 +76,6 @@ __device__ __forceinline__ int lds_atomic_inc_nodma(int* p) {
     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old) : "v"(a), "v"(one) : "memory");
     return old;
 }
-
 __device__ __forceinline__ void lds_atomic_max_u32_nodma(uint32_t* p, uint32_t v) {
     const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)p;
     asm volatile("ds_max_u32 %0, %1" : : "v"(a), "v"(v) : "memory");
@@ -119,6 +118,27 @@ __device__ __forceinline__ int xcd_remap(int b, int G) {
         j = j >= 32 ? 2 * (j - 32) + 1 : (j < m ? 2 * j : 2 * m + (j - m));
     }
     return base + j;
+}
+
+// Logical workgroup id -> (query block, corpus split) of the large-batch bf16 scans. Consecutive logical ids sit on
+// one XCD (xcd_remap), so the grouping decides what that XCD's L2 sees. gsz = query blocks per group:
+//   0: query-block-major — an XCD holds few query blocks x all splits (its query operands stay in L2, every
+//      workgroup streams its own part of the corpus);
+//   gsz >= 1: groups of gsz query blocks, split-major inside a group — an XCD holds a few splits x gsz query blocks:
+//      the gsz workgroups of one split stream the same corpus tiles (gsz = all query blocks: one or two splits per
+//      XCD, but then the query operands of all blocks no longer fit its L2).
+__device__ __forceinline__ void decode_block(int gsz, int S, int nqb, int logical, int& qb, int& split) {
+    if (gsz <= 0) { qb = logical / S; split = logical - qb * S; return; }
+    const int per = gsz * S, full = nqb / gsz;
+    if (logical < full * per) {
+        const int g = logical / per, w = logical - g * per;
+        split = w / gsz;
+        qb = g * gsz + (w - split * gsz);
+    } else {                                        // the last, smaller group
+        const int gl = nqb - full * gsz, w = logical - full * per;
+        split = w / gl;
+        qb = full * gsz + (w - split * gl);
+    }
 }
 
 // ---- pack_rows: row-major [n, d] (f32 / f16 / bf16) -> tiled, padded, swizzled fp32 ----------
@@ -202,9 +222,9 @@ struct ScanParams {
     // ceilI[q] < 0: that pass ran out of hits, nothing is admitted.
     const float* ceilD = nullptr;
     const int64_t* ceilI = nullptr;
-    int map = 0;         // bf16 large-batch scans: 0 = logical ids query-block-major (an XCD holds few query blocks x all
-                         // splits), 1 = split-major (an XCD holds one or two corpus splits x all query blocks: the
-                         // workgroups behind one L2 / the Infinity Cache stream the same corpus tiles)
+    int map = 0;         // bf16 large-batch scans: query blocks per group of decode_block (0 = query-block-major)
+    int nselect = 0;     // scan_bf16_w16_kernel: waves that run the episodes' selections (4 bytes of LDS per queue slot
+                         // each; the final sort takes 8: `nsortwaves`); 0 = nsortwaves
 };
 
 // bitonic sort, descending, of P (power of two) 64-bit keys in LDS by one wave
@@ -298,7 +318,7 @@ __device__ __forceinline__ void compact_query_select(const ScanParams& p, uint64
     const bool publish = pub_slot && n >= p.r;
     if (n <= p.k && !publish) return;
     const int kpl8 = (((n + 63) >> 6) + 7) & ~7;         // slots per lane, in batches of 8 (64 * kpl8 <= cap)
-    uint32_t* sh = (uint32_t*)scratch;                    // [64 * kpl8] high words; then [64 * kpl8] low words of tied keys
+    uint32_t* sh = (uint32_t*)scratch;                    // [64 * kpl8] high words, later (in place) the low words of tied keys
     const uint32_t* q32 = (const uint32_t*)queue;
 #pragma unroll 1
     for (int j0 = 0; j0 < kpl8; j0 += 8) {
@@ -331,11 +351,13 @@ __device__ __forceinline__ void compact_query_select(const ScanParams& p, uint64
     }
     uint32_t lcut = 0;
     if (tied > p.k - above) {
-        uint32_t* sl = sh + 64 * kpl8;
+        // in place: the high words are not needed again (the move below reads the keys from the queue), so the
+        // scratch of a selection is 4 bytes per queue slot
+        uint32_t* sl = sh;
 #pragma unroll 1
         for (int j = 0; j < kpl8; ++j) {
             const int i = lane + 64 * j;
-            sl[i] = sh[i] == v ? q32[2 * i] : 0u;
+            sl[i] = (i < n && sh[i] == v) ? q32[2 * i] : 0u;
         }
         wave_lds_sync();
         lcut = nth_largest_lds(sl, kpl8, lane, p.k - above);

@@ -48,10 +48,16 @@ for spec in os.environ.get("VARIANTS", "map1;v1;v2;v3;v4;map1,v1;map1,v2;map1,v3
             prm["bf16_shape16"] = 0
         elif tok.startswith("pp"):
             prm["bf16_pp"] = int(tok[2:])
+        elif tok.startswith("kc"):
+            prm["bf16_candidates"] = int(tok[2:])
+        elif tok.startswith("ring"):
+            prm["bf16_ring"] = int(tok[4:])
+        elif tok.startswith("occ"):
+            prm["bf16_occ"] = int(tok[3:])
         elif tok.startswith("ms"):
             prm["max_splits"] = int(tok[2:])
     variants.append((spec, prm))
-defaults = {"bf16_map": 0, "bf16_variant": 0, "bf16_waves": 0, "bf16_shape16": 1, "max_splits": 0, "bf16_pp": 0}
+defaults = {"bf16_map": 0, "bf16_variant": 0, "bf16_waves": 0, "bf16_shape16": 1, "max_splits": 0, "bf16_pp": 0, "bf16_ring": 0, "bf16_occ": 1, "bf16_candidates": 0}
 
 times = {name: [] for name, _ in variants}
 ref = None
@@ -69,6 +75,8 @@ for r in range(rounds + 1):
                 same = bool(torch.equal(I, ref[1])) and bool(torch.equal(D.view(torch.int32), ref[0].view(torch.int32)))
                 if not same:
                     print(f"!! variant {name}: results differ from base", flush=True)
+            print(f"   {name}: candidates {ix.last_bf16_stats()['candidates']}, repeated {ix.last_bf16_stats()['fallback_queries']}, "
+                  f"queue cap {ix.last_geometry()['queue_cap']}", flush=True)
             continue
         times[name].append(ix.last_timing()["scan_ms"])
 flops = 2.0 * nq * rows * 768

@@ -78,15 +78,18 @@ for c in range(cases):
                      ("bf16 8 waves", {"no_small_batch": 1, "bf16_waves": 8, "query_parts": int(rng.choice([1, 2]))}),
                      ("bf16 16 waves", {"no_small_batch": 1, "bf16_waves": 16, "query_parts": int(rng.choice([1, 2])),
                                         "bf16_shape16": int(rng.choice([0, 1])), "bf16_variant": int(rng.integers(0, 8)),
-                                        "bf16_map": int(rng.choice([0, 1]))}),
+                                        "bf16_map": int(rng.choice([0, 1, 2, 3, 7])), "bf16_ring": int(rng.choice([2, 3, 4])),
+                                        "bf16_occ": int(rng.choice([1, 2]))}),
                      # ping-pong kernels (both operands in LDS / corpus operand straight into registers); shapes they
                      # do not serve (odd K-stage counts, two query parts) fall back to the 16-wave kernel
                      ("bf16 ping-pong", {"no_small_batch": 1, "query_parts": 1, "bf16_pp": int(rng.choice([1, 2])),
                                          "bf16_map": int(rng.choice([0, 1]))}),
-                     ("bf16 direct corpus", {"no_small_batch": 1, "query_parts": 1, "bf16_pp": int(rng.choice([3, 4]))})]
+                     ("bf16 direct corpus", {"no_small_batch": 1, "query_parts": 1, "bf16_pp": int(rng.choice([3, 4])),
+                                             "bf16_map": int(rng.choice([0, 2, 5]))})]
     for name, params in variants:
-        for key in ("f32_scan", "no_small_batch", "query_parts", "bf16_waves", "bf16_variant", "bf16_map", "bf16_pp"):
+        for key in ("f32_scan", "no_small_batch", "query_parts", "bf16_waves", "bf16_variant", "bf16_map", "bf16_pp", "bf16_ring"):
             ix.set_param(key, 0)
+        ix.set_param("bf16_occ", 1)
         ix.set_param("bf16_shape16", 1)
         ix.set_param("small_f32_limit", 192)
         for key, val in params.items():

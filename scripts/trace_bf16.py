@@ -16,6 +16,9 @@ for lo in range(0, rows, 200000):
     ix.add(torch.randn((min(200000, rows - lo), 768), generator=g, device=dev))
 Q = torch.randn((nq, 768), generator=g, device=dev)
 ix.set_timing(True); ix.set_param("trace", 1); ix.set_param("query_parts", int(os.environ.get("QP", "0")))
+for kv in filter(None, os.environ.get("PARAMS", "").split(",")):      # e.g. PARAMS=bf16_ring=2,bf16_map=7
+    name, val = kv.split("=")
+    ix.set_param(name, int(val))
 for it in range(2):
     ix.search_device(Q, 100); torch.cuda.synchronize()
 import ctypes as C

@@ -301,7 +301,7 @@ def test_short_rows_many_runs_per_workgroup(R, storage, nq):
                                       (30000, 100, 260, 100), (70000, 384, 70, 256)])
 def test_large_batch_scan_variants_return_the_same_bits(R, n, d, nq, k):
     """Every large-batch bf16 scan (16 waves in both MFMA shapes and issue orders, 8 waves, the ping-pong kernel, the
-    direct-corpus-operand kernel, both workgroup mappings) on one index: the same bits as the oracle. Split caps
+    direct-corpus-operand kernel, ring depths, workgroup mappings) on one index: the same bits as the oracle. Split caps
     1 / 2 make a workgroup scan many tiles: compaction episodes, pipeline restarts, the split's meeting points."""
     X, Q = gaussian(61, (n, d)), gaussian(62, (nq, d))
     for storage, ref in (("bf16scan", X), ("bf16", bf16_round(X))):
@@ -310,10 +310,12 @@ def test_large_batch_scan_variants_return_the_same_bits(R, n, d, nq, k):
         ix.set_param("query_parts", 1)
         for ms in (2, 0, 1):
             ix.set_param("max_splits", ms)
-            for prm in ({}, {"bf16_shape16": 0}, {"bf16_shape16": 0, "bf16_variant": 2}, {"bf16_shape16": 0, "bf16_variant": 3},
+            for prm in ({}, {"bf16_ring": 3}, {"bf16_ring": 4, "bf16_map": 2}, {"bf16_ring": 2, "bf16_map": 7}, {"bf16_ring": 2, "bf16_occ": 2},
+                        {"bf16_shape16": 0}, {"bf16_shape16": 0, "bf16_variant": 2}, {"bf16_shape16": 0, "bf16_variant": 3},
                         {"bf16_shape16": 0, "bf16_variant": 5, "bf16_map": 1}, {"bf16_waves": 8}, {"bf16_pp": 1},
-                        {"bf16_pp": 2, "bf16_map": 1}, {"bf16_pp": 3}, {"bf16_pp": 4}):
-                for key, val in {"bf16_shape16": 1, "bf16_variant": 0, "bf16_map": 0, "bf16_waves": 0, "bf16_pp": 0, **prm}.items():
+                        {"bf16_pp": 2, "bf16_map": 1}, {"bf16_pp": 3, "bf16_map": 3}, {"bf16_pp": 4}):
+                for key, val in {"bf16_shape16": 1, "bf16_variant": 0, "bf16_map": 0, "bf16_waves": 0, "bf16_pp": 0, "bf16_ring": 0,
+                                 "bf16_occ": 1, **prm}.items():
                     ix.set_param(key, val)
                 D, I = ix.search(Q, k)
                 assert ix.last_bf16_stats()["candidates"] > 0
