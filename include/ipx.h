@@ -186,8 +186,8 @@ int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k
  *   "small_f32_limit" : fp32 scans of up to this many queries use the 32/64-query tile that
  *                  streams the corpus at the HBM rate (default 192; results do not depend on it).
  *   "no_small_batch" : 1 = always use the 256-query tiles (A/B measurements, tests).
- *   "bf16_waves" : large-batch bf16 scan with 8 or 16 waves per workgroup (0 = automatic: 16 with
- *                  one query part, 8 with two; results do not depend on it).
+ *   "bf16_waves" : large-batch bf16 scan with 8 or 16 waves per workgroup (0 = automatic: 16; results do not
+ *                  depend on it).
  *   "bf16_shape16" : the 16-wave bf16 scan uses v_mfma_f32_16x16x32_bf16 (1, default: measured 2-4 % faster
  *                  on the 8.8M x 768 workload) or v_mfma_f32_32x32x16_bf16 (0).
  *   "bf16_ring"  : LDS stage-ring depth of the 16-wave bf16 scan: 2 (default: one stage in flight — measured 10 %

@@ -584,7 +584,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     // CU) can be chosen
     const bool w16_1 = !small && ix->bf16_pp == 0 &&
                        ((qparts == 1 && (ix->bf16_waves == 16 || ix->bf16_waves == 0) && ix->bf16_shape16) ||
-                        (qparts == 2 && ix->bf16_waves == 16));
+                        (qparts == 2 && (ix->bf16_waves == 16 || ix->bf16_waves == 0)));
     // Ring depth. Two stages (one in flight) measured fastest on the 8.8M x 768 x 6980-query workload: 84 ms against
     // 93 ms with four — the workgroups that stream the same corpus split then keep each other in step through L2
     // (a workgroup that runs ahead misses L2 and waits on HBM, its followers hit), L2 fetch traffic per launch
@@ -607,7 +607,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
                            : (qparts == 2 ? ipx::HCfg<4, 2>::RING : ipx::HCfg<4, 1>::RING);
     // LDS for the episodes: the stage ring's bytes, or for the 16-wave kernel (one workgroup per CU, so the CU's LDS
     // is its own) at least 128 KiB whatever the ring depth
-    const bool w16k = !small && (ix->bf16_waves == 16 || (ix->bf16_waves == 0 && qparts == 1)) && ix->bf16_pp == 0;
+    const bool w16k = !small && (ix->bf16_waves == 16 || ix->bf16_waves == 0) && ix->bf16_pp == 0;
     const int sort_bytes = w16k && occ == 1 ? std::max(ring, 128 * 1024) : ring;
     const int nsortwaves = std::max(1, std::min(8, sort_bytes / (cap * 8)));
     const int nselect = w16k ? std::max(1, std::min(16, sort_bytes / (cap * 4))) : 0;
@@ -669,9 +669,10 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     p.nselect = nselect;
     const int lds = std::max({ring, nsortwaves * cap * 8, nselect * cap * 4}) + ipx::LDS_STATE_BYTES;
     {
-        // one query part: the 16-wave variant is 9 % faster (8.8M x 768, 6980 queries: 93 vs 102 ms);
-        // hi + lo parts: no difference, the 8-wave kernel stays
-        const bool w16 = !small && (ix->bf16_waves == 16 || (ix->bf16_waves == 0 && qparts == 1));
+        // large batches: the 16-wave kernel (8.8M x 768, 6980 queries, one query part: 93 vs 102 ms for the 8-wave
+        // kernel at the same ring depth; hi + lo parts at depth 1000, whole search: 197 ms with the 2-deep ring, 203
+        // with 3, 217 on 8 waves)
+        const bool w16 = !small && (ix->bf16_waves == 16 || ix->bf16_waves == 0);
         void (*kern)(const ipx::ScanParams, const int) =
             small ? (qparts == 2 ? ipx::scan_bf16_kernel<1, 2> : ipx::scan_bf16_kernel<1, 1>)
             : w16 ? (qparts == 2 ? ipx::scan_bf16_w16_kernel<2, false>

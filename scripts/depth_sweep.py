@@ -27,7 +27,7 @@ Q = torch.randn((nq, 768), generator=g, device=dev)
 
 
 def run(k, **prm):
-    defaults = {"f32_scan": 0, "query_parts": 0, "bf16_candidates": 0}
+    defaults = {"f32_scan": 0, "query_parts": 0, "bf16_candidates": 0, "bf16_waves": 0, "bf16_ring": 0}
     for key, val in {**defaults, **prm}.items():
         ix.set_param(key, val)
     best = 1e9
@@ -46,7 +46,9 @@ for k in [int(x) for x in os.environ.get("KS", "500,700,800,900,1000,1024").spli
     t_f, _, ref = run(k, f32_scan=1)
     line = [f"k={k:5d}  fp32 {t_f:8.1f} ms"]
     for name, prm in (("default", {}), ("1part/2048", {"query_parts": 1, "bf16_candidates": 2048}),
-                      ("2part/2048", {"query_parts": 2, "bf16_candidates": 2048})):
+                      ("2part/2048", {"query_parts": 2, "bf16_candidates": 2048}),
+                      ("2part/16 waves", {"query_parts": 2, "bf16_waves": 16, "bf16_ring": 3}),
+                      ("2part/16 waves/ring 2", {"query_parts": 2, "bf16_waves": 16, "bf16_ring": 2})):
         if prm.get("bf16_candidates", 0) and prm["bf16_candidates"] < k:
             continue
         t, st, out = run(k, **prm)
