@@ -1537,12 +1537,6 @@ int ipx_read_trace(ipx_index* ix, uint64_t* out, int max_workgroups) {
     if (ix->last_kc > 0 && max_workgroups >= 2 * ix->last_wgs)   // bf16 scan: episode split follows
         IPX_HIP(hipMemcpy(out + (size_t)n * 4, (uint64_t*)ix->trace.p + (size_t)ix->last_wgs * 4,
                           (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-#ifdef IPX_STAMPS
-    // diagnostic build: per-wave cycle sums follow the workgroup records
-    if (max_workgroups >= 5 * ix->last_wgs)
-        IPX_HIP(hipMemcpy(out + (size_t)n * 4, (uint64_t*)ix->trace.p + (size_t)ix->last_wgs * 4,
-                          (size_t)n * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-#endif
     return 0;
 }
 

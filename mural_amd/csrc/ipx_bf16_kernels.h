@@ -207,11 +207,7 @@ template <int QW, int QP> struct HCfg {
     static constexpr int STAGE_B = PART_B * QP;
     static constexpr int STAGE = HSTAGE_A + STAGE_B;     // 32 / 48 KiB (QW 4), 20 / 24 KiB (QW 1)
     static constexpr int NBUF = QW == 4 ? (QP == 1 ? 4 : 3) : 6;      // LDS stage ring (<= 144 KiB)
-#ifdef IPX_ABL_NO_B_COPY      // diagnostic build: the query stage is never copied (results are meaningless)
-    static constexpr int LOADS = 2;
-#else
     static constexpr int LOADS = 2 + (QW == 4 ? 2 * QP : 1);          // LDS-DMA pieces per thread per stage
-#endif
     static constexpr int RING = NBUF * STAGE;
 };
 
@@ -236,9 +232,7 @@ struct StagePieces {
     // piece i of HCfg::LOADS: 0, 1 = the A rounds; 2.. = the B rounds (8 KiB apart)
     __device__ __forceinline__ void issue(int i) const {
         if (i < 2) IPX_GLDS(ga + i * 8192, la + i * 8192);
-#ifndef IPX_ABL_NO_B_COPY
         else IPX_GLDS(gb + (i - 2) * 8192, lb + (i - 2) * 8192);
-#endif
     }
 };
 
@@ -270,11 +264,7 @@ template <int QW>
 __device__ __forceinline__ void read_b(f32x4 (&b)[QW], uint32_t bb) {
     IPX_DS_READ_B128(b[0], bb, 0);
     if constexpr (QW == 4) {
-#ifdef IPX_ABL_HALF_B_READS   // diagnostic build: a third fewer operand reads from LDS (results are meaningless)
-        IPX_DS_READ_B128(b[1], bb, 2048);
-#else
         IPX_DS_READ_B128(b[1], bb, 2048); IPX_DS_READ_B128(b[2], bb, 4096); IPX_DS_READ_B128(b[3], bb, 6144);
-#endif
     }
 }
 // s_waitcnt lgkmcnt(N) that the compiler sees as (re)defining the operand registers waited for, so
@@ -311,11 +301,7 @@ __device__ __forceinline__ void mfma_set(f32x16 (&acc)[2][QW], const f32x4 (&a)[
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < QW; ++j)
-#ifdef IPX_ABL_HALF_B_READS
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[i]), as_bf16x8(b[j & 1]), acc[i][j], 0, 0, 0);
-#else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[i]), as_bf16x8(b[j]), acc[i][j], 0, 0, 0);
-#endif
     pin_acc<QW>(acc);
 }
 
@@ -415,7 +401,6 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
     // optional trace (ipx_set_param "trace"): wave 0's view of where the time goes
     uint64_t tr_epi = 0, tr_sort = 0, tr_begin = 0, tr_w1 = 0, tr_own = 0, tr_w2 = 0;
     uint32_t tr_appends = 0, tr_episodes = 0;
-    uint64_t tr_vm = 0, tr_bar = 0;
     if (p.trace) tr_begin = __builtin_readcyclecounter();
     while (cur[0].ok) {
         const int t = cur[0].t;
@@ -431,11 +416,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             const int nslot = slot + 1 == NBUF ? 0 : slot + 1;
             const uint32_t buf = smem_base + slot * STAGE;
             const uint32_t nbuf = smem_base + nslot * STAGE;
-#ifdef IPX_ABL_HALF_B_READS
-            constexpr int NB = QW == 4 ? 2 : QW;
-#else
             constexpr int NB = QW;                 // LDS reads per B operand set
-#endif
             if constexpr (QP == 1) {
                 // first half: set 1 is read while set 0 (read one half-stage ago) is multiplied
                 read_a<QW>(A[1], buf + a_off + pc1);
@@ -465,27 +446,14 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             __builtin_amdgcn_sched_barrier(0);
             // the stage's last operands are in registers (so nobody reads its buffer any more), the
             // next stage has landed (NBUF - 2 younger stages may still be in flight)
-#ifdef IPX_ABL_HALF_B_READS
-#define IPX_MFMA1(i_, j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A[1][i_]), as_bf16x8(B[1][(j_) & 1]), acc[i_][j_], 0, 0, 0)
-#else
 #define IPX_MFMA1(i_, j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A[1][i_]), as_bf16x8(B[1][j_]), acc[i_][j_], 0, 0, 0)
-#endif
             // the addresses of the next copy pieces are worked out before the barrier, and the first
             // MFMAs of the last phase go out right behind it: the matrix core has work queued while
             // this wave issues the next stage's operand reads
             const StagePieces<QW, QP> sp(p, smem + slot * STAGE, cur[NBUF].t, qb, cur[NBUF].ks, wave, lane);
             __builtin_amdgcn_sched_barrier(0);
-#ifdef IPX_STAMP_BARRIER     // diagnostic build: cycles wave 0 spends in the per-stage wait + barrier
-            const uint64_t tb0 = __builtin_readcyclecounter();
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
-            const uint64_t tb1 = __builtin_readcyclecounter();
-            __builtin_amdgcn_s_barrier();
-            tr_vm += tb1 - tb0;
-            tr_bar += __builtin_readcyclecounter() - tb1;
-#else
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
             __builtin_amdgcn_s_barrier();
-#endif
             __builtin_amdgcn_sched_barrier(0);
             // last phase, in pinned issue order: two MFMAs, the next stage's first operand reads (they
             // have the rest of the phase to land), then the copy pieces of the stage NBUF ahead
@@ -537,14 +505,6 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
 
         // ---- epilogue: threshold filter, rare append to the per-query queues ----
         ++tiles_done;
-#ifdef IPX_ABL_NO_EPILOGUE    // diagnostic build: the bare MFMA pipeline (results are meaningless)
-        {
-            float m = 0.f;
-            for (int i = 0; i < 2; ++i) for (int j = 0; j < QW; ++j) for (int r = 0; r < 16; ++r) m += acc[i][j][r];
-            if (m == 12345.678f) *p.err = 2;
-            continue;
-        }
-#endif
         uint64_t tr_e0 = 0;
         if (p.trace) tr_e0 = __builtin_readcyclecounter();
         const int docbase = t * HBD + wd * 64 + 4 * h;
@@ -665,7 +625,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             tr[1] = tr_epi;
             tr[2] = tr_sort;
             uint64_t* tx = p.trace + (size_t)gridDim.x * 4 + (size_t)blockIdx.x * 4;   // episode split (wave 0)
-            tx[0] = tr_w1; tx[1] = tr_own; tx[2] = tr_w2 | (tr_vm << 32); tx[3] = tr_bar;
+            tx[0] = tr_w1; tx[1] = tr_own; tx[2] = tr_w2; tx[3] = 0;
             atomicAdd((unsigned long long*)(tr + 3), (unsigned long long)tr_episodes);
         }
     }

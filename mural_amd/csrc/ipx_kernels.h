@@ -14,6 +14,7 @@
 //      read group hit 16 different 16-byte slots of the 256-byte bank row).
 //   d is zero-padded to a multiple of 16, the row count to a multiple of R.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -447,10 +448,6 @@ scan_f32_kernel(const ScanParams p) {
     const int h = lane >> 5, l31 = lane & 31;
 
     uint64_t t_start = 0;
-#ifdef IPX_STAMPS
-    uint64_t st_bar = 0, st_begin = 0, st_epi = 0, st_filter = 0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_begin) :: "memory");
-#endif
     if (p.trace) t_start = __builtin_amdgcn_s_memrealtime();
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -517,8 +514,13 @@ scan_f32_kernel(const ScanParams p) {
 
     const int sw = (lane >> 2) & 3;
     const int a_off = (wd * 64 + l31) * 64;     // byte offset of this lane's doc row in a stage
-    const int b_off = STAGE_A_BYTES + (wq * 128 + l31) * 64;
+    // Query groups of 32 are dealt to the two wave columns alternately (group 2j + wq is wave column wq's j-th), so
+    // the live groups of a ragged last block spread over both columns.
+    const int b_off = STAGE_A_BYTES + (wq * 32 + l31) * 64;
     const int pc0 = ((0 + h) ^ sw) * 16, pc1 = ((2 + h) ^ sw) * 16;
+    const int nreal = p.nq - qb * BQ < BQ ? p.nq - qb * BQ : BQ;            // real queries of this block
+    int nj = (nreal - wq * 32 + 63) / 64;                                    // live groups of this wave column
+    nj = nj < 0 ? 0 : (nj > 4 ? 4 : nj);
 
     // ---- which tiles this workgroup scans ----------------------------------------------------
     // The corpus is cut into runs of R tiles. The S workgroups of a query block take runs from a
@@ -579,9 +581,13 @@ scan_f32_kernel(const ScanParams p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) a0[i] = *(const f32x4*)(smem + a_off + i * 2048 + pc0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b0[j] = *(const f32x4*)(smem + b_off + j * 2048 + pc0);
+    for (int j = 0; j < 4; ++j) b0[j] = *(const f32x4*)(smem + b_off + j * 4096 + pc0);
 
     int g = 0;
+    // The tile loop, instantiated per number of live 32-query groups of this wave (NJ): the last query block of a
+    // batch is usually ragged (6980 queries = 27 blocks + 68), and its all-padding groups are not multiplied.
+    auto scan_tiles = [&](auto nj_const) {
+    constexpr int NJ = decltype(nj_const)::value;
     while (c0.ok) {
         const int t = c0.t;
         if (t == enter_t) claim_next_run();
@@ -599,59 +605,54 @@ scan_f32_kernel(const ScanParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) a1[i] = *(const f32x4*)(buf + a_off + i * 2048 + pc1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b1[j] = *(const f32x4*)(buf + b_off + j * 2048 + pc1);
+            for (int j = 0; j < NJ; ++j) b1[j] = *(const f32x4*)(buf + b_off + j * 4096 + pc1);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], b0[j][kk], acc[i][j], 0, 0, 0);
             // issue order: the six LDS reads of set 1 first, then the MFMAs that cover them
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+            if constexpr (NJ == 4) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+            }
 
             // keep the 32 MFMAs above the barrier (hipcc would sink them below it and expose
             // the LDS read latency of set 1)
             __builtin_amdgcn_sched_barrier(0);
-#ifdef IPX_STAMPS
-            uint64_t s1, s2;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s1) :: "memory");
-            __syncthreads();
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s2) :: "memory");
-            st_bar += s2 - s1;
-#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-#endif
             // No branches from here to the end of the stage, so hipcc can spread the copy
             // issue and the LDS reads among the 32 MFMAs.
             issue_stage(p, smem + (g & 1) * STAGE_BYTES, c2.t, qb, c2.ks, wave, lane);
 #pragma unroll
             for (int i = 0; i < 2; ++i) a0[i] = *(const f32x4*)(nbuf + a_off + i * 2048 + pc0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b0[j] = *(const f32x4*)(nbuf + b_off + j * 2048 + pc0);
+            for (int j = 0; j < NJ; ++j) b0[j] = *(const f32x4*)(nbuf + b_off + j * 4096 + pc0);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], b1[j][kk], acc[i][j], 0, 0, 0);
             // issue order below the barrier: MFMAs start at once; the six copy pieces, then the
             // six LDS reads of the next stage's set 0, go out between pairs of MFMAs
+            if constexpr (NJ == 4) {
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-            }
+                for (int u = 0; u < 6; ++u) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                for (int u = 0; u < 6; ++u) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             __builtin_amdgcn_sched_barrier(0);
             c0 = c1;
             c1 = c2;
@@ -661,10 +662,6 @@ scan_f32_kernel(const ScanParams p) {
         // c0's set-0 operands are in registers, c1's copy is in flight
 
         // ---- epilogue: threshold filter, rare append to the per-query queues ----
-#ifdef IPX_STAMPS
-        uint64_t e0;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e0) :: "memory");
-#endif
         ++tiles_done;
         const int docbase = t * BD + wd * 64 + 4 * h;
         // flag raised by the PREVIOUS tile's appends: every wave of the workgroup reads the same
@@ -672,8 +669,8 @@ scan_f32_kernel(const ScanParams p) {
         bool episode = lds_read_i32_nodma(&flags[(tiles_done + 1) & 1]) != 0;
         int* myflag = &flags[tiles_done & 1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ql = wq * 128 + j * 32 + l31;
+        for (int j = 0; j < NJ; ++j) {
+            const int ql = (2 * j + wq) * 32 + l31;
             const float tau = lds_read_f32_nodma(&taus[ql]);
             float m = acc[0][j][0];
 #pragma unroll
@@ -709,11 +706,6 @@ scan_f32_kernel(const ScanParams p) {
                     }
             }
         }
-#ifdef IPX_STAMPS
-        uint64_t em;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(em) :: "memory");
-        st_filter += em - e0;
-#endif
         // Episodes (workgroup-uniform decisions, no per-tile barrier):
         //  * compaction when a queue is filling up (flag of the previous tile: at most 2*BD more
         //    appends land before it runs, and fill_limit leaves room for them) and after
@@ -741,11 +733,14 @@ scan_f32_kernel(const ScanParams p) {
         } else if ((tiles_done & 1) == 0 && is_pow4(tiles_done >> 1)) {
             poll_union_threshold(p, taus, qb, tid);
         }
-#ifdef IPX_STAMPS
-        uint64_t e1;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e1) :: "memory");
-        st_epi += e1 - e0;
-#endif
+    }
+    };
+    switch (nj) {
+        case 4: scan_tiles(std::integral_constant<int, 4>{}); break;
+        case 3: scan_tiles(std::integral_constant<int, 3>{}); break;
+        case 2: scan_tiles(std::integral_constant<int, 2>{}); break;
+        case 1: scan_tiles(std::integral_constant<int, 1>{}); break;
+        default: scan_tiles(std::integral_constant<int, 0>{}); break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tail's dummy copies write LDS too
     __syncthreads();
@@ -757,14 +752,6 @@ scan_f32_kernel(const ScanParams p) {
     // ---- anything left to help with? ----
     if (p.helpers <= 0 || !pick_block()) break;
   }
-#ifdef IPX_STAMPS
-    if (p.trace && lane == 0) {   // diagnostic build: per-wave cycle sums
-        uint64_t s_end;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_end) :: "memory");
-        uint64_t* tr = p.trace + (size_t)gridDim.x * 4 + ((size_t)blockIdx.x * 4 + wave) * 4;
-        tr[0] = s_end - st_begin; tr[1] = st_filter; tr[2] = st_bar; tr[3] = st_epi;
-    }
-#endif
     if (p.trace && tid == 0) {
         uint64_t* tr = p.trace + (size_t)blockIdx.x * 4;
         tr[0] = t_start;

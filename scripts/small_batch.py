@@ -3,6 +3,9 @@ Prints per-search wall time (device-resident inputs), the kernel split and the c
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from mural_amd import _lib
+if os.environ.get("IPX_LIB"):      # an ablation / diagnostic build next to libipx.so
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["IPX_LIB"])
 from mural_amd.faiss_retriever.retriever import FlatIPIndex
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 12_500_000
 storage = sys.argv[2] if len(sys.argv) > 2 else "bf16"

@@ -35,6 +35,3 @@ print(f"per WG mean: total {tot.mean():.3e} ticks, filter {epi.mean()/tot.mean()
       f"appends {app.mean():.0f} ({app.mean()/tiles:.1f}/tile), episodes {eps.mean():.1f} (max {eps.max():.0f})")
 print(f"episode split (wave 0, share of total): wait for the other waves' filters {ex[:,0].mean()/tot.mean():.3f}, own compaction {ex[:,1].mean()/tot.mean():.3f}, "
       f"wait for the other waves' compaction {ex[:,2].mean()/tot.mean():.3f}")
-if os.environ.get("IPX_LIB"):
-    vm = (raw[n:, 2] >> np.uint64(32)).astype(np.float64); bar = ex[:, 3]
-    print(f"per-stage waits (wave 0, share of total): vmcnt {vm.mean()/tot.mean():.3f}, barrier {bar.mean()/tot.mean():.3f}")
