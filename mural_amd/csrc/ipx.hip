@@ -80,6 +80,13 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// Every entry point that works on a GPU: the index's device for the duration of the call, the caller's afterwards
+// (faiss leaves the caller's current device alone too).
+#define IPX_ON_DEVICE(dev_)                                                                                       \
+    DeviceGuard ipx_guard_(dev_);                                                                                 \
+    if (ipx_guard_.err != hipSuccess)                                                                             \
+        return fail(IPX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(ipx_guard_.err))
+
 // Address of the static workspace on `device` (which must be current). Resolved once per device.
 int scratch_ptr(int device, void** out) {
     if (device < 0 || device >= IPX_MAX_DEVICES) return fail(IPX_ERR_ARG, "device index beyond " + std::to_string(IPX_MAX_DEVICES));
@@ -924,7 +931,7 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
     if (nq == 0) return 0;
     if (!q_src || !out_D || !out_I || (A > 0 && !w)) return fail(IPX_ERR_ARG, "search: null pointer");
     if (nq > (int64_t)0x7fffff00) return fail(IPX_ERR_ARG, "search: nq too large for one call");
-    IPX_HIP(hipSetDevice(ix->device));
+    IPX_ON_DEVICE(ix->device);
     hipStream_t st = (hipStream_t)stream;
     const int d = ix->d;
     const size_t nout = (size_t)nq * k;
@@ -1103,7 +1110,7 @@ int ipx_create(int d, int device, ipx_index** out) {
 
 int ipx_destroy(ipx_index* ix) {
     if (!ix) return 0;
-    (void)hipSetDevice(ix->device);
+    DeviceGuard guard(ix->device);
     if (ix->Xp) (void)hipFree(ix->Xp);
     if (ix->Xh) (void)hipFree(ix->Xh);
     for (DevBuf* b : {&ix->Qp, &ix->cand, &ix->partD, &ix->partI, &ix->err, &ix->stageIn, &ix->stageQ, &ix->stageW,
@@ -1124,7 +1131,7 @@ int64_t ipx_ntotal(const ipx_index* ix) { return ix ? ix->ntotal : 0; }
 
 int ipx_reserve(ipx_index* ix, int64_t n) {
     if (!ix || n < 0) return fail(IPX_ERR_ARG, "reserve: bad argument");
-    IPX_HIP(hipSetDevice(ix->device));
+    IPX_ON_DEVICE(ix->device);
     return grow_storage(ix, n, nullptr);
 }
 
@@ -1141,7 +1148,7 @@ int ipx_add(ipx_index* ix, const void* rows, int64_t n, int dtype, int on_device
     if (n == 0) return 0;
     if (!rows) return fail(IPX_ERR_ARG, "add: null rows");
     if (ix->ntotal + n > (int64_t)0x7fffff00) return fail(IPX_ERR_ARG, "add: more than 2^31 rows in one index");
-    IPX_HIP(hipSetDevice(ix->device));
+    IPX_ON_DEVICE(ix->device);
     hipStream_t st = (hipStream_t)stream;
     if (int rc = grow_storage(ix, ix->ntotal + n, st)) return rc;
     const size_t row_bytes = (size_t)ix->d * dtype_size(dtype);
@@ -1277,7 +1284,7 @@ static int pool_impl(ipx_index* ix, const char* who, const float* hidden, int64_
     if (n < 0 || n > 0x7fffffff) return fail(IPX_ERR_ARG, std::string(who) + ": n outside [0, 2^31)");
     if (n == 0) return 0;
     if (!hidden || !W || !b) return fail(IPX_ERR_ARG, std::string(who) + ": null pointer");
-    IPX_HIP(hipSetDevice(ix->device));
+    IPX_ON_DEVICE(ix->device);
     const int d = ix->d;
     const hipMemcpyKind in = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     // keep [CLS] and the A aspect rows of every sequence: [n][1 + A][d]
@@ -1353,7 +1360,7 @@ int ipx_merge_topk(const float* D, const int64_t* I, int S, int64_t nq, int k_in
     if (nq == 0) return 0;
     if ((S > 0 && (!D || !I)) || !out_D || !out_I) return fail(IPX_ERR_ARG, "merge: null pointer");
     if (nq > 0x7fffffffLL) return fail(IPX_ERR_ARG, "merge: nq too large");
-    IPX_HIP(hipSetDevice(device));
+    IPX_ON_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     const size_t nin = (size_t)S * nq * k_in, nout = (size_t)nq * k_out;
     const float* dD = D;
@@ -1422,7 +1429,7 @@ int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k
     if (nq == 0) return 0;
     if ((S > 0 && !packed) || !out_D || !out_I) return fail(IPX_ERR_ARG, "merge_packed: null pointer");
     if (nq > 0x7fffffffLL) return fail(IPX_ERR_ARG, "merge_packed: nq too large");
-    IPX_HIP(hipSetDevice(device));
+    IPX_ON_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     const size_t block = ipx_packed_block_bytes(nq, k_in);
     const int64_t* I = (const int64_t*)packed;
@@ -1530,7 +1537,7 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
 int ipx_read_trace(ipx_index* ix, uint64_t* out, int max_workgroups) {
     if (!ix || !out) return fail(IPX_ERR_ARG, "read_trace: null argument");
     if (!ix->trace_on || !ix->trace.p) return fail(IPX_ERR_STATE, "read_trace: tracing is off (set_param trace 1)");
-    IPX_HIP(hipSetDevice(ix->device));
+    IPX_ON_DEVICE(ix->device);
     const int n = std::min(max_workgroups, ix->last_wgs);
     IPX_HIP(hipDeviceSynchronize());
     IPX_HIP(hipMemcpy(out, ix->trace.p, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -1542,7 +1549,7 @@ int ipx_read_trace(ipx_index* ix, uint64_t* out, int max_workgroups) {
 
 int ipx_check(ipx_index* ix, void* stream) {
     if (!ix) return fail(IPX_ERR_ARG, "check: null index");
-    IPX_HIP(hipSetDevice(ix->device));
+    IPX_ON_DEVICE(ix->device);
     hipStream_t st = (hipStream_t)stream;
     int errflag = 0;
     if (ix->last_err) IPX_HIP(hipMemcpyAsync(&errflag, ix->last_err, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1560,7 +1567,7 @@ int ipx_set_timing(ipx_index* ix, int enabled) {
 int ipx_last_timing(ipx_index* ix, float* pack_ms, float* scan_ms, float* merge_ms) {
     if (!ix) return fail(IPX_ERR_ARG, "last_timing: null index");
     if (!ix->ev_valid) return fail(IPX_ERR_STATE, "last_timing: no timed search recorded (call ipx_set_timing first)");
-    IPX_HIP(hipSetDevice(ix->device));
+    IPX_ON_DEVICE(ix->device);
     IPX_HIP(hipEventSynchronize(ix->ev[ix->ev_rescore ? 4 : ix->ev_merge ? 3 : 2]));
     float a = 0.f, b = 0.f, c = 0.f;
     IPX_HIP(hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]));
@@ -1576,7 +1583,7 @@ int ipx_last_bf16_stats(ipx_index* ix, float* rescore_ms, int* candidates, int64
     if (!ix) return fail(IPX_ERR_ARG, "last_bf16_stats: null index");
     float r = 0.f;
     if (rescore_ms && ix->ev_valid && ix->ev_rescore) {
-        IPX_HIP(hipSetDevice(ix->device));
+        IPX_ON_DEVICE(ix->device);
         IPX_HIP(hipEventSynchronize(ix->ev[4]));
         IPX_HIP(hipEventElapsedTime(&r, ix->ev[3], ix->ev[4]));
     }

@@ -371,6 +371,7 @@ def _spawn_ranks(argv, n_ranks, entry=None):
     import socket
     import subprocess
     import sys
+    import time
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -381,9 +382,16 @@ def _spawn_ranks(argv, n_ranks, entry=None):
                    MASTER_PORT=str(port), IPX_GPUS="1")
         procs.append(subprocess.Popen(entry + list(argv), env=env))
     status = 0
+    # IPX_SPAWN_TIMEOUT (seconds, optional): a launch whose ranks have not all finished by then is ended with
+    # status 124 instead of waiting for ever on a collective that cannot complete
+    limit = float(os.environ.get("IPX_SPAWN_TIMEOUT", "0") or 0)
+    deadline = time.monotonic() + limit if limit > 0 else None
     try:
         for proc in procs:
-            rc = proc.wait()
+            try:
+                rc = proc.wait(timeout=max(deadline - time.monotonic(), 0.0) if deadline else None)
+            except subprocess.TimeoutExpired:
+                rc = 124
             if rc != 0 and status == 0:
                 status = rc
                 for other in procs:           # a rank failed: the others would wait in a collective for ever

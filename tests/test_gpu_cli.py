@@ -114,3 +114,4 @@ def test_per_shard_runs_and_reducer_main_equal_the_single_index_run(drv, tmp_pat
     assert merged.read_bytes() == single.read_bytes()
     assert merged.read_bytes() == _expected_ranking(Q, np.concatenate(Xs), k, [f"{7000 + i}" for i in range(nq)],
                                                     list(range(int(base[-1]))))
+
