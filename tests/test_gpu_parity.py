@@ -55,6 +55,8 @@ def assert_bit_exact(D, I, Q, X, k, id_base=0):
     (9000, 17, 64, 2048, 2),           # largest k, odd d
     (777, 768, 1, 100, 1), (777, 768, 19, 10, 1), (777, 768, 20, 10, 1), (777, 768, 21, 10, 1),
     (128, 16, 256, 128, 1), (129, 16, 257, 5, 1), (1, 8, 3, 4, 1),
+    # ragged last query block: 160 / 200 / 97 real queries = 3+2 / 4+3 / 2+2 live 32-query groups per wave column
+    (6000, 48, 416, 50, 1), (6000, 48, 456, 7, 2), (3000, 96, 353, 100, 1),
 ])
 def test_search_matches_oracle(R, n, d, nq, k, adds):
     X, Q = gaussian(1234, (n, d)), gaussian(4321, (nq, d))
