@@ -722,8 +722,8 @@ scan_f32_kernel(const ScanParams p) {
             ++n_compact;
             if (tid < 2) flags[tid] = 0;
             for (int ql = wave; ql < BQ; ql += 4)
-                compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, false, 0, 0,
-                              mypub ? mypub + ql : nullptr);
+                compact_query_select(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
+                                     mypub ? mypub + ql : nullptr);
             __syncthreads();
             poll_union_threshold(p, taus, qb, tid);
             issue_stage(p, smem + (g & 1) * STAGE_BYTES, c0.t, qb, c0.ks, wave, lane);
