@@ -128,6 +128,8 @@ struct ipx_index {
     DevBuf Qp, cand, partD, partI, err, stageIn, stageQ, stageW, outD, outI, trace, pub;
     DevBuf maxsq, qfused, candD, candI, flags, sel, qsel, selD, selI, poolH, poolW, poolQ;
     DevBuf deepD, deepI, ceilD, ceilI;   // deep searches: one pass's lists, the next pass's ceilings
+    int* hflags = nullptr;               // pinned host copy of a pass's margin flags + the error word
+    size_t hflags_n = 0;
     void* pinned = nullptr;          // host staging of ipx_add (two slices)
     size_t pinned_bytes = 0;
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
@@ -624,7 +626,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     if (int rc = ix->err.ensure(256)) return rc;
     if (int rc = ix->candD.ensure(ncand * sizeof(float))) return rc;
     if (int rc = ix->candI.ensure(ncand * sizeof(int64_t))) return rc;
-    if (int rc = ix->flags.ensure((size_t)nq * sizeof(int))) return rc;
+    if (int rc = ix->flags.ensure((size_t)(nq + 1) * sizeof(int))) return rc;      // + the error word (rescore_kernel)
     if (S > 1) {
         if (int rc = ix->partD.ensure(ncand * S * sizeof(float))) return rc;
         if (int rc = ix->partI.ensure(ncand * S * sizeof(int64_t))) return rc;
@@ -745,6 +747,8 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     rp.outD = dD;
     rp.outI = dI;
     rp.flags = (int*)ix->flags.p;
+    rp.err = (const int*)ix->err.p;
+    rp.nq = (int)nq;
     rp.id_base = ix->id_base;
     rp.acc_coef = margin_acc_coef(ix->nks_h * ipx::HBK, qparts);
     rp.qparts = qparts;
@@ -769,13 +773,24 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
         ix->last_kc = kc;
     }
 
-    // which queries failed the margin check? (the one host round trip of a pass)
-    std::vector<int> flags((size_t)nq);
-    int errflag = 0;
-    IPX_HIP(hipMemcpyAsync(flags.data(), ix->flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st));
-    IPX_HIP(hipMemcpyAsync(&errflag, ix->err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    // which queries failed the margin check? (the one host round trip of a pass: the flags and, behind them, the
+    // scan's error word, which the rescoring kernel copies there — one copy into pinned memory, one wait)
+    if (ix->hflags_n < (size_t)nq + 1) {
+        if (ix->hflags) (void)hipHostFree(ix->hflags);
+        ix->hflags = nullptr;
+        ix->hflags_n = 0;
+        const size_t want = std::max<size_t>((size_t)nq + 1, 4096);
+        hipError_t e = hipHostMalloc((void**)&ix->hflags, want * sizeof(int), hipHostMallocDefault);
+        if (e != hipSuccess) { ix->hflags = nullptr; return fail(IPX_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+        ix->hflags_n = want;
+    }
+    const int* flags = ix->hflags;
+    IPX_HIP(hipMemcpyAsync(ix->hflags, ix->flags.p, (size_t)(nq + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     IPX_HIP(hipStreamSynchronize(st));
-    if (errflag) return fail(IPX_ERR_STATE, "search: candidate queue overflow (internal invariant violated)");
+    if (flags[nq]) {
+        (void)hipMemsetAsync(ix->err.p, 0, 256, st);
+        return fail(IPX_ERR_STATE, "search: candidate queue overflow (internal invariant violated)");
+    }
     flagged.clear();
     for (int64_t i = 0; i < nq; ++i)
         if (flags[(size_t)i]) flagged.push_back((int)i);
@@ -837,6 +852,8 @@ int exact_rows_path(ipx_index* ix, const float* qf, const std::vector<int>& sel,
     rp.outD = (float*)ix->partD.p;
     rp.outI = (int64_t*)ix->partI.p;
     rp.flags = (int*)ix->deepD.p;
+    rp.err = nullptr;
+    rp.nq = 0;
     rp.id_base = ix->id_base;
     rp.acc_coef = 1.f;
     rp.qparts = 1;
@@ -972,8 +989,10 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
                            (int64_t)nout);
         IPX_HIP(hipGetLastError());
     } else {
+        // the error word is cleared when it is allocated and whenever it was found set: no fill per search
+        const bool fresh = ix->err.p == nullptr;
         if (int rc = ix->err.ensure(256)) return rc;
-        IPX_HIP(hipMemsetAsync(ix->err.p, 0, 256, st));
+        if (fresh) IPX_HIP(hipMemsetAsync(ix->err.p, 0, 256, st));
         ix->last_err = (int*)ix->err.p;
         // bf16 scan whenever the index keeps a bf16 copy and the candidate list (2k with hi + lo
         // query parts, 1.25k on bf16 rows) fits IPX_MAX_K; deeper searches take the fp32 scan,
@@ -1122,6 +1141,7 @@ int ipx_destroy(ipx_index* ix) {
     for (auto& e : ix->ev_stage)
         if (e) (void)hipEventDestroy(e);
     if (ix->pinned) (void)hipHostFree(ix->pinned);
+    if (ix->hflags) (void)hipHostFree(ix->hflags);
     delete ix;
     return 0;
 }
@@ -1554,7 +1574,10 @@ int ipx_check(ipx_index* ix, void* stream) {
     int errflag = 0;
     if (ix->last_err) IPX_HIP(hipMemcpyAsync(&errflag, ix->last_err, sizeof(int), hipMemcpyDeviceToHost, st));
     IPX_HIP(hipStreamSynchronize(st));
-    if (errflag) return fail(IPX_ERR_STATE, "search: candidate queue overflow (internal invariant violated)");
+    if (errflag) {
+        (void)hipMemsetAsync(ix->last_err, 0, sizeof(int), st);
+        return fail(IPX_ERR_STATE, "search: candidate queue overflow (internal invariant violated)");
+    }
     return 0;
 }
 

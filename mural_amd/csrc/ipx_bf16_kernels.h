@@ -667,7 +667,9 @@ struct RescoreParams {
     const uint32_t* maxsq;   // float bits of max_x |x|^2 and max_x |x - bf16(x)|^2
     float* outD;             // [nq][k]
     int64_t* outI;           // [nq][k]
-    int* flags;              // [nq]
+    int* flags;              // [nq] (+ 1 when err is given)
+    const int* err;          // optional: the scan's error word, copied to flags[nq] so that one readback brings both
+    int nq;                  // queries of the pass (position of that copy)
     int64_t id_base;
     float acc_coef;          // accumulation-error coefficient (host: margin_acc_coef)
     int qparts;              // bf16 parts of the query the scan used (1: hi, 2: hi + lo)
@@ -734,6 +736,7 @@ rescore_kernel(const RescoreParams p) {
         }
         s_m = m;
         p.flags[qi] = flag;
+        if (p.err && qi == 0) p.flags[p.nq] = *p.err;      // the scans are done: same stream
     }
     __syncthreads();
     const int m = s_m;
