@@ -128,6 +128,10 @@ struct ipx_index {
     DevBuf Qp, cand, partD, partI, err, stageIn, stageQ, stageW, outD, outI, trace, pub;
     DevBuf maxsq, qfused, candD, candI, flags, sel, qsel, selD, selI, poolH, poolW, poolQ;
     DevBuf deepD, deepI, ceilD, ceilI;   // deep searches: one pass's lists, the next pass's ceilings
+    // Smallest depth at which the margin rule sent most of a batch to the fp32 scan (storage 1): a few rows with a far
+    // larger norm than the rest widen every query's margin, the bf16 passes are then wasted work, and searches at that
+    // depth or beyond go to the fp32 scan directly. Forgotten when rows are added or a parameter changes.
+    int bf16_fail_k = INT32_MAX;
     int* hflags = nullptr;               // pinned host copy of a pass's margin flags + the error word
     size_t hflags_n = 0;
     void* pinned = nullptr;          // host staging of ipx_add (two slices)
@@ -922,7 +926,11 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     std::vector<int> flagged;
     if (int rc = bf16_pass(ix, qf, nq, k, kc, qparts, dD, dI, st, true, flagged)) return rc;
     ix->last_fallback = (int64_t)flagged.size();
-    if (!flagged.empty() && (kc < IPX_MAX_K || qparts == 1)) {    // longest list, hi + lo query
+    // most of a batch failed with a list that is already half the longest one: the repeat pass would fail too
+    const bool hopeless = ix->storage == 1 && nq >= 64 && (int64_t)flagged.size() * 2 > nq && 2 * kc > IPX_MAX_K &&
+                          ix->force_kc == 0;
+    if (hopeless) ix->bf16_fail_k = std::min(ix->bf16_fail_k, k);
+    if (!flagged.empty() && !hopeless && (kc < IPX_MAX_K || qparts == 1)) {    // longest list, hi + lo query
         std::vector<int> still;
         int rc = redo_queries(ix, qf, flagged, k, dD, dI, st, [&](const float* q2, int64_t n2, float* D2, int64_t* I2) {
             return bf16_pass(ix, q2, n2, k, IPX_MAX_K, 2, D2, I2, st, false, still);
@@ -1001,7 +1009,8 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
             return fail(IPX_ERR_ARG, "search: bf16 storage serves k <= " + std::to_string(IPX_MAX_K * 4 / 5) +
                         " (the candidate list is 1.25 k); use storage 0 or 1 for deeper searches");
         const bool bf16 = ix->storage == 2 ||
-                          (ix->storage == 1 && !ix->force_f32_scan && (2 * k <= IPX_MAX_K || ix->force_kc > 0));
+                          (ix->storage == 1 && !ix->force_f32_scan && (2 * k <= IPX_MAX_K || ix->force_kc > 0) &&
+                           (k < ix->bf16_fail_k || ix->force_kc > 0));
         int rc = bf16 ? scan_bf16_path(ix, dq, dw, A, logits, nq, k, dD, dI, st)
                  : k > IPX_MAX_K ? scan_f32_deep(ix, dq, dw, A, logits, nq, k, dD, dI, st)
                                  : scan_f32_path(ix, dq, dw, A, logits, nq, k, dD, dI, st, true);
@@ -1170,6 +1179,7 @@ int ipx_add(ipx_index* ix, const void* rows, int64_t n, int dtype, int on_device
     if (ix->ntotal + n > (int64_t)0x7fffff00) return fail(IPX_ERR_ARG, "add: more than 2^31 rows in one index");
     IPX_ON_DEVICE(ix->device);
     hipStream_t st = (hipStream_t)stream;
+    ix->bf16_fail_k = INT32_MAX;          // new rows, new norm bounds
     if (int rc = grow_storage(ix, ix->ntotal + n, st)) return rc;
     const size_t row_bytes = (size_t)ix->d * dtype_size(dtype);
     if (on_device) {
@@ -1467,6 +1477,7 @@ int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k
 
 int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
     if (!ix || !name) return fail(IPX_ERR_ARG, "set_param: null argument");
+    ix->bf16_fail_k = INT32_MAX;
     if (!strcmp(name, "max_splits")) {
         if (value < 0 || value > 65536) return fail(IPX_ERR_ARG, "set_param: max_splits outside [0, 65536]");
         ix->max_splits = (int)value;
