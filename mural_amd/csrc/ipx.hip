@@ -149,7 +149,7 @@ struct ipx_index {
     int query_parts = 0;     // 0 = automatic; 1 / 2 bf16 parts per query in the bf16 scan
     int small_f32_limit = 192;     // fp32 scans of up to this many queries take scan_f32_small_kernel
     bool bf16_shape16 = true;      // 16-wave scan, one query part: v_mfma_f32_16x16x32_bf16 (measured 2-4 % faster) / 32x32x16
-    int f32_helpers = 8;           // fp32 large-tile scan: helper list slots per query block (0 = no work stealing)
+    int f32_helpers = 16;           // fp32 large-tile scan: helper list slots per query block (0 = no work stealing)
     int run_tiles = 0;             // fp32 large-tile scan: corpus tiles per run of the dynamic split (0 = automatic)
     int bf16_pp = 0;               // large-batch bf16 scan, one query part: 1 / 2 = ping-pong kernel (2: with s_setprio)
     int bf16_map = 0;              // large-batch bf16 scan: ScanParams::map
