@@ -305,6 +305,7 @@ def test_large_batch_scan_variants_return_the_same_bits(R, n, d, nq, k):
     1 / 2 make a workgroup scan many tiles: compaction episodes, pipeline restarts, the split's meeting points."""
     X, Q = gaussian(61, (n, d)), gaussian(62, (nq, d))
     for storage, ref in (("bf16scan", X), ("bf16", bf16_round(X))):
+        rD, rI = O.topk_total_order(O.scores_mfma_order(Q, ref), k)      # the oracle once per index, not per variant
         ix = index(R, X, storage, adds=2)
         ix.set_param("no_small_batch", 1)
         ix.set_param("query_parts", 1)
@@ -319,7 +320,8 @@ def test_large_batch_scan_variants_return_the_same_bits(R, n, d, nq, k):
                     ix.set_param(key, val)
                 D, I = ix.search(Q, k)
                 assert ix.last_bf16_stats()["candidates"] > 0
-                assert_bits(D, I, Q, ref, k)
+                assert np.array_equal(I, rI), (ms, prm, np.argwhere(I != rI)[:3].tolist())
+                assert np.array_equal(D.view(np.uint32), rD.view(np.uint32)), (ms, prm)
 
 
 def test_randomised_differential_cases(R):
