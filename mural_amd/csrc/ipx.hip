@@ -884,6 +884,10 @@ int exact_rows_path(ipx_index* ix, const float* qf, const std::vector<int>& sel,
     return 0;
 }
 
+// Longest candidate list of a bf16 pass (the API's single-pass depth IPX_MAX_K is about result lists; candidate
+// lists may be longer: their queues live in HBM, a selection takes 4 bytes of LDS per queue slot, the final sort 8).
+constexpr int MAX_KC = 4096;
+
 // bf16 scan + exact rescoring. Queries that fail the margin check are repeated with the longest
 // candidate list, and whatever still fails goes to the fp32 scan (storage 1 keeps fp32 rows) or to the exact pass over
 // the bf16 rows (storage 2).
@@ -900,19 +904,22 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     // publish just its best score (scan_bf16_kernel, fast1).
     // Measured on the 8.8M x 768 Gaussian workload, storage 1, large batches: one part with 3k candidates
     // beats two parts with 2k (k = 500: 129 vs 190 ms; k = 700 with 2048: 154 vs 199 ms, nothing repeated;
-    // at 2.1k every query was) — so one part as long as 3.2k fits the longest list, its list 5k capped there.
+    // at 2.1k every query was). Round 2, candidate lists up to 4096: k = 1000 one part with 3072 188 ms against 202 ms
+    // for two parts with 2000, k = 800 185 vs 195 ms, nothing repeated; with 4096 it is slower again (212 ms: the
+    // appends and selections grow with the list). So: one part for every depth the bf16 path serves, its list 5k
+    // while that stays within 2048, else 3k.
     const int mult1 = ix->storage == 2 ? 2 : 5;
     const bool small = nq <= 64 && !ix->no_small_batch;
-    const bool one_part_fits = ix->storage == 2 ? 2 * k <= 1024 : 11 * k <= 4 * (int)IPX_MAX_K;
+    const bool one_part_fits = ix->storage == 2 ? 2 * k <= 1024 : 3 * k <= 3072;
     int qparts = ix->query_parts > 0 ? ix->query_parts : ((small || !one_part_fits) ? 2 : 1);
     int kc = ix->force_kc > 0 ? ix->force_kc
-             : qparts == 1 ? std::max(256, mult1 * k)
+             : qparts == 1 ? std::max(256, ix->storage == 2 ? mult1 * k : std::min(mult1 * k, std::max(2048, 3 * k)))
              : ix->storage == 2 ? std::max(256, k + k / 4)
              // two parts, fp32 rows: 2k candidates, 3k for shallow lists (measured, small batches: at k = 150 a
              // list of 300 left 2 of 32 queries to the repeat pass, 450 none; from k = 250 on 2k leaves none);
              // 256 (the number of splits: every split publishes just its best score) while that is >= 2.5k
                            : std::max(256, 5 * k <= 2 * 256 ? 256 : (k <= 256 ? 3 * k : 2 * k));
-    kc = std::min(std::max(kc, k), (int)IPX_MAX_K);
+    kc = std::min(std::max(kc, k), MAX_KC);
 
     const float* qf = dq;
     if (A > 0) {   // the fused fp32 query is needed row-major for the rescoring
@@ -927,13 +934,13 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     if (int rc = bf16_pass(ix, qf, nq, k, kc, qparts, dD, dI, st, true, flagged)) return rc;
     ix->last_fallback = (int64_t)flagged.size();
     // most of a batch failed with a list that is already half the longest one: the repeat pass would fail too
-    const bool hopeless = ix->storage == 1 && nq >= 64 && (int64_t)flagged.size() * 2 > nq && 2 * kc > IPX_MAX_K &&
+    const bool hopeless = ix->storage == 1 && nq >= 64 && (int64_t)flagged.size() * 2 > nq && 2 * kc > MAX_KC &&
                           ix->force_kc == 0;
     if (hopeless) ix->bf16_fail_k = std::min(ix->bf16_fail_k, k);
-    if (!flagged.empty() && !hopeless && (kc < IPX_MAX_K || qparts == 1)) {    // longest list, hi + lo query
+    if (!flagged.empty() && !hopeless && (kc < MAX_KC || qparts == 1)) {    // longest list, hi + lo query
         std::vector<int> still;
         int rc = redo_queries(ix, qf, flagged, k, dD, dI, st, [&](const float* q2, int64_t n2, float* D2, int64_t* I2) {
-            return bf16_pass(ix, q2, n2, k, IPX_MAX_K, 2, D2, I2, st, false, still);
+            return bf16_pass(ix, q2, n2, k, MAX_KC, 2, D2, I2, st, false, still);
         });
         if (rc) return rc;
         for (int& i : still) i = flagged[(size_t)i];
@@ -1554,7 +1561,7 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
         return 0;
     }
     if (!strcmp(name, "bf16_candidates")) {
-        if (value < 0 || value > IPX_MAX_K) return fail(IPX_ERR_ARG, "set_param: bf16_candidates outside [0, IPX_MAX_K]");
+        if (value < 0 || value > 4096) return fail(IPX_ERR_ARG, "set_param: bf16_candidates outside [0, 4096]");
         ix->force_kc = (int)value;
         return 0;
     }

@@ -47,8 +47,8 @@ for k in [int(x) for x in os.environ.get("KS", "500,700,800,900,1000,1024").spli
     line = [f"k={k:5d}  fp32 {t_f:8.1f} ms"]
     for name, prm in (("default", {}), ("1part/2048", {"query_parts": 1, "bf16_candidates": 2048}),
                       ("2part/2048", {"query_parts": 2, "bf16_candidates": 2048}),
-                      ("2part/16 waves", {"query_parts": 2, "bf16_waves": 16, "bf16_ring": 3}),
-                      ("2part/16 waves/ring 2", {"query_parts": 2, "bf16_waves": 16, "bf16_ring": 2})):
+                      ("1part/3072", {"query_parts": 1, "bf16_candidates": 3072}),
+                      ("1part/4096", {"query_parts": 1, "bf16_candidates": 4096})):
         if prm.get("bf16_candidates", 0) and prm["bf16_candidates"] < k:
             continue
         t, st, out = run(k, **prm)

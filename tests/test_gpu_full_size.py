@@ -80,7 +80,7 @@ def test_headline_corpus_8p8m_fp32(R):
     # (the planted rows have 3x the norm of the others: they set the margin rule's corpus-wide bound, and at this
     #  depth every query then goes on to the repeat pass / the fp32 scan — the bits must not depend on the route;
     #  without plants scripts/depth_sweep.py measures 0 repeats at k = 1000)
-    assert ix.last_bf16_stats()["candidates"] == 2000 and ix.last_bf16_stats()["fallback_queries"] == nq
+    assert ix.last_bf16_stats()["candidates"] == 3000 and ix.last_bf16_stats()["fallback_queries"] == nq
     # ... and the index remembers: the next search at this depth goes to the fp32 scan directly (no wasted bf16
     # passes), shallower ones stay on the bf16 scan
     Dk3, Ik3 = ix.search_device(Q, 1000)
