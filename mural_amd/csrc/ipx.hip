@@ -612,18 +612,21 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     const int nruns = (ntiles + R - 1) / R;
     S = std::min(S, nruns);
     const int G = nqb * S;
-    // queue: kc survivors of a compaction + 2 tiles of appends before the next one runs + room to fill
+    const bool w16k = !small && (ix->bf16_waves == 16 || ix->bf16_waves == 0) && ix->bf16_pp == 0;
+    // queue: kc survivors of a compaction + 2 tiles of appends before the next one runs + room to fill, rounded up to a
+    // power of two (a capacity cut to the next multiple of 512 was measured at kc = 3000: 5120 instead of 8192 slots
+    // gives the selections two more waves but forces extra episodes — 176 vs 146 ms of scan)
     const int cap = next_pow2(kc + 2 * ipx::HBD + kc / 2);
+    const int cap_sort = next_pow2(cap);
     const int ring = small ? (qparts == 2 ? ipx::HCfg<1, 2>::RING : ipx::HCfg<1, 1>::RING)
                      : w16_ring == 2 ? (qparts == 2 ? ipx::WCfg<2, 2>::RING : ipx::WCfg<1, 2>::RING)
                      : (w16_ring == 3 && qparts == 1) ? ipx::WCfg<1, 3>::RING
                            : (qparts == 2 ? ipx::HCfg<4, 2>::RING : ipx::HCfg<4, 1>::RING);
     // LDS for the episodes: the stage ring's bytes, or for the 16-wave kernel (one workgroup per CU, so the CU's LDS
-    // is its own) at least 128 KiB whatever the ring depth
-    const bool w16k = !small && (ix->bf16_waves == 16 || ix->bf16_waves == 0) && ix->bf16_pp == 0;
-    const int sort_bytes = w16k && occ == 1 ? std::max(ring, 128 * 1024) : ring;
-    const int nsortwaves = std::max(1, std::min(8, sort_bytes / (cap * 8)));
-    const int nselect = w16k ? std::max(1, std::min(16, sort_bytes / (cap * 4))) : 0;
+    // is its own) 157 KiB whatever the ring depth
+    const int sort_bytes = w16k && occ == 1 ? std::max(ring, 157 * 1024) : ring;
+    const int nsortwaves = std::max(1, std::min(8, sort_bytes / (cap_sort * 8)));
+    const int nselect = w16k ? std::max(1, std::min(16, sort_bytes / ((cap + ipx::W16_SEL_AUX) * 4))) : 0;
 
     if (int rc = ix->Qp.ensure((size_t)nqb * nks * stage_b)) return rc;
     if (int rc = ix->cand.ensure((size_t)G * bq * cap * sizeof(uint64_t))) return rc;
@@ -680,7 +683,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     p.ntiles = ntiles;
     p.map = small ? 0 : ix->bf16_map == 1 ? nqb : ix->bf16_map;      // 1 = one group of all query blocks
     p.nselect = nselect;
-    const int lds = std::max({ring, nsortwaves * cap * 8, nselect * cap * 4}) + ipx::LDS_STATE_BYTES;
+    const int lds = std::max({ring, nsortwaves * cap_sort * 8, nselect * (cap + ipx::W16_SEL_AUX) * 4}) + ipx::LDS_STATE_BYTES;
     {
         // large batches: the 16-wave kernel (8.8M x 768, 6980 queries, one query part: 93 vs 102 ms for the 8-wave
         // kernel at the same ring depth; hi + lo parts at depth 1000, whole search: 197 ms with the 2-deep ring, 203

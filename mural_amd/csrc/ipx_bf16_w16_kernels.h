@@ -10,6 +10,10 @@
 
 namespace ipx {
 
+// Entries of a selection's side list per selecting wave (compact_query_select; a wave's scratch is 4 bytes per queue
+// slot + this list).
+constexpr int W16_SEL_AUX = 1024;
+
 template <int QP, int NB = 0> struct WCfg {
     static constexpr int THREADS = 1024;
     static constexpr int PART_B = 256 * 64;                  // one part of the query stage: 16 KiB
@@ -67,9 +71,12 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the state words sit behind whichever is largest: the ring, the final sorts' scratch, the selections' scratch
     // (the host sizes the allocation by the same rule)
+    // (the queue capacity is a multiple of 512 here, not a power of two: the final sort rounds it up)
+    int sort_cap = 512;
+    while (sort_cap < p.cap) sort_cap <<= 1;
     int stage_region = C::RING;
-    if (nsortwaves * p.cap * 8 > stage_region) stage_region = nsortwaves * p.cap * 8;
-    if (p.nselect * p.cap * 4 > stage_region) stage_region = p.nselect * p.cap * 4;
+    if (nsortwaves * sort_cap * 8 > stage_region) stage_region = nsortwaves * sort_cap * 8;
+    if (p.nselect * (p.cap + W16_SEL_AUX) * 4 > stage_region) stage_region = p.nselect * (p.cap + W16_SEL_AUX) * 4;
     int* cnts = (int*)(smem + stage_region);
     float* taus = (float*)(smem + stage_region + BQ_ * 4);
     int* flags = (int*)(smem + stage_region + 2 * BQ_ * 4);
@@ -93,7 +100,7 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
     const int fill_limit = p.cap - 2 * HBD;
 
     uint64_t* myqueues = p.cand + (size_t)blockIdx.x * BQ_ * p.cap;
-    uint64_t* scratch = (uint64_t*)smem + (size_t)wave * p.cap;
+    uint64_t* scratch = (uint64_t*)smem + (size_t)wave * sort_cap;
     const int nselect = p.nselect > 0 ? p.nselect : nsortwaves;
 
     const int sw = (lane >> 2) & 3;
@@ -342,8 +349,9 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
             if (tid < 2) flags[tid] = 0;
             if (wave < nselect)
                 for (int ql = wave; ql < BQ_; ql += nselect)
-                    compact_query_select(p, (uint64_t*)((uint32_t*)smem + (size_t)wave * p.cap), cnts, taus,
-                                         myqueues + (size_t)ql * p.cap, ql, lane, mypub ? mypub + ql : nullptr);
+                    compact_query_select(p, (uint64_t*)((uint32_t*)smem + (size_t)wave * (p.cap + W16_SEL_AUX)), cnts, taus,
+                                         myqueues + (size_t)ql * p.cap, ql, lane, mypub ? mypub + ql : nullptr,
+                                         (uint32_t*)smem + (size_t)wave * (p.cap + W16_SEL_AUX) + p.cap, W16_SEL_AUX);
             __syncthreads();
             if (tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
             Walker wr = w0;

@@ -294,27 +294,76 @@ __device__ __forceinline__ void compact_query(const ScanParams& p, uint64_t* scr
 // resolved the same way on the low words (row ids); the survivors move to the front of the queue
 // in place (every position written lies below every position still to be read). All memory
 // traffic goes in batches of 8 independent accesses per lane: the cost is latency, not volume.
-__device__ __forceinline__ uint32_t nth_largest_lds(const uint32_t* sh, int kpl8, int lane, int need) {
+// count of entries >= cand among sh[0 .. 64 * kpl8), by wave ballots (kpl8 a multiple of 8)
+__device__ __forceinline__ int count_ge_lds(const uint32_t* sh, int kpl8, int lane, uint32_t cand) {
+    int cnt = 0;
+#pragma unroll 1
+    for (int j0 = 0; j0 < kpl8; j0 += 8) {
+        uint32_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = sh[lane + 64 * (j0 + u)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cnt += __popcll(__ballot(x[u] >= cand));
+    }
+    return cnt;
+}
+
+// The need-th largest of sh[0 .. 64 * kpl8) (empty slots are 0), bit by bit from the top. Two levels: the upper 16
+// bits are decided over all entries; then only the entries that share those 16 bits can still matter — they are
+// copied to `aux` (with the count of the entries above them) and the lower 16 bits are decided over that short list
+// (scores of one candidate list lie close together: a few dozen entries per 16-bit bucket out of thousands). If the
+// bucket does not fit `aux`, the lower bits are decided over all entries as well. sh is left untouched.
+__device__ __forceinline__ uint32_t nth_largest_lds(const uint32_t* sh, int kpl8, int lane, int need, uint32_t* aux, int aux_cap) {
     uint32_t t = 0;
 #pragma unroll 1
-    for (int b = 31; b >= 0; --b) {
+    for (int b = 31; b >= 16; --b) {
+        const uint32_t cand = t | (1u << b);
+        if (count_ge_lds(sh, kpl8, lane, cand) >= need) t = cand;
+    }
+    const uint32_t top = t >> 16;
+    int above = 0, m = 0;
+#pragma unroll 1
+    for (int j = 0; j < kpl8; ++j) {
+        const uint32_t x = sh[lane + 64 * j];
+        const bool match = (x >> 16) == top;
+        above += __popcll(__ballot((x >> 16) > top));
+        const uint64_t mask = __ballot(match);
+        const int at = m + __popcll(mask & ((1ull << lane) - 1));
+        if (match && at < aux_cap) aux[at] = x;
+        m += __popcll(mask);
+    }
+    if (m > aux_cap) {                         // the bucket is too large for the side list: all entries again
+#pragma unroll 1
+        for (int b = 15; b >= 0; --b) {
+            const uint32_t cand = t | (1u << b);
+            if (count_ge_lds(sh, kpl8, lane, cand) >= need) t = cand;
+        }
+        return t;
+    }
+    wave_lds_sync();
+    const int need2 = need - above;            // >= 1: the upper bits were chosen so that fewer than `need` lie above
+    const int rounds = (m + 63) >> 6;
+#pragma unroll 1
+    for (int b = 15; b >= 0; --b) {
         const uint32_t cand = t | (1u << b);
         int cnt = 0;
 #pragma unroll 1
-        for (int j0 = 0; j0 < kpl8; j0 += 8) {
-            uint32_t x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = sh[lane + 64 * (j0 + u)];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) cnt += __popcll(__ballot(x[u] >= cand));
+        for (int j = 0; j < rounds; ++j) {
+            const int i = lane + 64 * j;
+            const uint32_t x = i < m ? aux[i] : 0u;
+            cnt += __popcll(__ballot(x >= cand));
         }
-        if (cnt >= need) t = cand;
+        if (cnt >= need2) t = cand;
     }
+    wave_lds_sync();                           // the side list is free again (the next selection reuses it)
     return t;
 }
 
+// `aux` / `aux_cap`: the selections' side list; nullptr = the second half of a scratch of 8 bytes per queue slot.
 __device__ __forceinline__ void compact_query_select(const ScanParams& p, uint64_t* scratch, int* cnts, float* taus,
-                                                     uint64_t* queue, int ql, int lane, uint32_t* pub_slot) {
+                                                     uint64_t* queue, int ql, int lane, uint32_t* pub_slot,
+                                                     uint32_t* aux = nullptr, int aux_cap = 0) {
+    if (!aux) { aux = (uint32_t*)scratch + p.cap; aux_cap = p.cap; }
     const int n = cnts[ql];
     const bool publish = pub_slot && n >= p.r;
     if (n <= p.k && !publish) return;
@@ -337,11 +386,11 @@ __device__ __forceinline__ void compact_query_select(const ScanParams& p, uint64
     }
     wave_lds_sync();
     if (publish) {
-        const uint32_t vr = nth_largest_lds(sh, kpl8, lane, p.r);
+        const uint32_t vr = nth_largest_lds(sh, kpl8, lane, p.r, aux, aux_cap);
         if (lane == 0) __hip_atomic_store(pub_slot, vr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (n <= p.k) return;
-    const uint32_t v = nth_largest_lds(sh, kpl8, lane, p.k);      // >= 1: empty slots (0) never pass
+    const uint32_t v = nth_largest_lds(sh, kpl8, lane, p.k, aux, aux_cap);      // >= 1: empty slots (0) never pass
     // ties at the cut: only the (k - #above) tied keys with the largest low words survive
     int above = 0, tied = 0;
 #pragma unroll 1
@@ -361,7 +410,7 @@ __device__ __forceinline__ void compact_query_select(const ScanParams& p, uint64
             sl[i] = (i < n && sh[i] == v) ? q32[2 * i] : 0u;
         }
         wave_lds_sync();
-        lcut = nth_largest_lds(sl, kpl8, lane, p.k - above);
+        lcut = nth_largest_lds(sl, kpl8, lane, p.k - above, aux, aux_cap);
     }
     int base = 0;
 #pragma unroll 1

@@ -20,7 +20,7 @@ for kv in filter(None, os.environ.get("PARAMS", "").split(",")):      # e.g. PAR
     name, val = kv.split("=")
     ix.set_param(name, int(val))
 for it in range(2):
-    ix.search_device(Q, 100); torch.cuda.synchronize()
+    ix.search_device(Q, int(os.environ.get("K", "100"))); torch.cuda.synchronize()
 import ctypes as C
 from mural_amd import _lib
 n = ix.last_geometry()["workgroups"]
