@@ -1,0 +1,56 @@
+"""bench.py's output contract (one JSON line on stdout with the keys the driver reads), on a small corpus: the
+headline mode with its roofline and cpu_baseline objects, and the cfg5 mode (BASELINE.json configs[4]) on a 1-rank
+RCCL group. Runs bench.py as a child process, as the driver does."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                   # ONE line
+    return json.loads(lines[0])
+
+
+def test_headline_line_has_the_contract_keys():
+    j = _bench("--rows", "400000", "--queries", "600", "--steps", "2", "--warmup", "1", "--cpu-sample-rows", "50000")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True
+    assert j["unit"] == "queries/s" and j["dtype"] == "f32" and j["vs_baseline"] is None and "workload" in j["config"]
+    assert abs(j["value"] - 600 / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - 2.0 * 600 * 400000 * 768 / (r["kernel_ms"] * 1e-3) / 1e12) <= 1e-6 * r["achieved"]
+    assert r["traffic"] is None and "traffic_source" in r            # the PMC figure belongs to the full-size workload
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "queries/s" and c["value"] > 0 and c["cores"] >= 1 and "threads" in c["sample"]
+    b = j["extra"]["bf16scan"]                                       # same index, bf16 scan: identical bits
+    assert b["bit_identical_to_f32_scan"] is True and b["roofline"]["bound"] == "mfma"
+    assert j["extra"]["depth_1000"]["bit_identical"] is True
+    assert {x["queries"] for x in j["extra"]["small_batch_f32_rows"]} == {1, 16, 64}
+
+
+def test_cfg5_line():
+    j = _bench("--workload", "cfg5", "--cfg5-rows", "600000", "--steps", "3", "--warmup", "1")
+    assert j["scaling"] == "weak" and j["n_gpus"] == 1 and j["unit"] == "queries/s" and j["roofline"]["bound"] == "hbm"
+    rows = j["extra"]["cfg5"]["batches"]
+    assert [r["queries"] for r in rows] == [1, 2, 4, 8, 16, 32, 64]
+    for r in rows:
+        assert r["ms_per_search"] > 0 and r["scan_ms"] > 0 and r["ms_per_search"] >= r["scan_ms"] * 0.9
+        assert abs(r["roofline"]["achieved"] - 600000 * 768 * 2 / (r["scan_ms"] * 1e-3) / 1e9) <= 1e-6 * r["roofline"]["achieved"]
+    assert abs(j["value"] - rows[-1]["queries_per_s"]) <= 1e-9 * j["value"]
