@@ -139,7 +139,7 @@ def run_cfg5(torch, dist, dev, local_rank, rank, world, d, k, rows_per_rank, ste
     return {"what": f"BASELINE.json configs[4]: {world} rank(s) x {rows_per_rank} x {d} bf16 rows generated on the device "
                     f"(storage bf16), top-{k}, {steps} searches per batch size; ms_per_search is end to end on every rank "
                     f"(local scan + rescoring, one all-gather of packed (ids, scores) blocks over "
-                    f"{'RCCL' if world > 1 else 'a 1-rank NCCL group'}, GPU merge), max over ranks; "
+                    f"{'RCCL' if world > 1 else ('a 1-rank NCCL group' if dist.is_initialized() else 'no process group: merge only')}, GPU merge), max over ranks; "
                     f"exchange_merge_us = that minus the same search without exchange",
             "ranks": world, "rows_per_rank": rows_per_rank, "total_rows": world * rows_per_rank,
             "shard_build_s": round(t_build, 2), "batches": rows}
@@ -191,9 +191,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29517")
-    # (one rank: a 1-rank NCCL group, so the cfg5 measurement runs its all-gather through RCCL)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if world == 1:
+        # one rank: a 1-rank NCCL group on a free port, so the cfg5 measurement runs its all-gather through RCCL; if
+        # that cannot be set up the run goes on without a group (the exchange then is the merge alone)
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        try:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        except Exception as exc:      # noqa: BLE001 - any failure here only removes the 1-rank collective
+            print(f"bench: no 1-rank process group ({exc}); continuing without", file=sys.stderr, flush=True)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.workload == "cfg5":
         res = run_cfg5(torch, dist, dev, local_rank, rank, world, args.dim, args.k, args.cfg5_rows,
@@ -211,7 +221,8 @@ def main():
                            "rows_per_rank": args.cfg5_rows, "dim": args.dim, "k": args.k,
                            "parallelism": f"row-shard x{world}"},
                 "roofline": b64["roofline"], "cpu_baseline": None, "extra": {"cfg5": res}})
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
         return
 
     os.environ["IPX_STORAGE"] = args.storage
@@ -399,7 +410,8 @@ def main():
         if extra:
             out["extra"] = extra
         emit(out)
-    dist.destroy_process_group()
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
