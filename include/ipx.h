@@ -178,6 +178,10 @@ int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k
  *                  list holds: thousands of duplicate rows, a degenerate embedding) are repeated — storage 1: on
  *                  the fp32 scan; storage 2: by an exact pass over every stored row, slow but never an error.
  *                  A zero query needs no repeat (all scores are exactly 0: rows in ascending order).
+ *                  Storage 1 keeps rows far longer than the rest (|x|^2 above 4 x the mean of the first rows added;
+ *                  NaN / inf rows too; at most 256 of them, more count as ordinary rows) out of the bf16 scan: every
+ *                  search scores them exactly on the side and merges them in, so they do not widen the other rows'
+ *                  margin. Same results, bit for bit.
  *   "bf16_candidates" : candidates per query the bf16 scan keeps (0 = automatic).
  *   "query_parts": bf16 parts per query in the bf16 scan: 1 = bf16(q); 2 = hi + lo (16 bits of
  *                  the query, twice the MFMA work, a far smaller margin); 0 = automatic.
@@ -217,6 +221,10 @@ int ipx_last_timing(ipx_index* idx, float* pack_ms, float* scan_ms, float* merge
  * ipx_set_timing), candidates kept per query (0 = the fp32 scan ran), and how many queries
  * failed the sufficiency check of the first pass and were repeated. Any output may be NULL. */
 int ipx_last_bf16_stats(ipx_index* idx, float* rescore_ms, int* candidates, int64_t* fallback_queries);
+
+/* Rows of a storage-1 index the bf16 scan leaves to the side list (see "storage"), as of the most recent bf16
+ * search. No counterpart in the reference; bookkeeping for tests. */
+int ipx_outlier_rows(const ipx_index* idx);
 
 /* Launch geometry chosen by the most recent search: workgroups, corpus splits per
  * query block, candidate-queue capacity. For bench / DESIGN.md bookkeeping. */

@@ -126,6 +126,9 @@ struct ipx_index {
     int64_t cap_tiles_h = 0; // tiles of 256 rows the bf16 buffer holds
     uint16_t* Xh = nullptr;  // packed bf16 corpus (storage 1, 2)
     DevBuf Qp, cand, partD, partI, err, stageIn, stageQ, stageW, outD, outI, trace, pub;
+    DevBuf outl, olist, sideD, sideI;   // outlier rows of an index with fp32 rows + bf16 copy (row_sumsq_max_kernel)
+    bool outl_thr_set = false;
+    int n_outliers = 0;                 // as of the last bf16 pass
     DevBuf maxsq, qfused, candD, candI, flags, sel, qsel, selD, selI, poolH, poolW, poolQ;
     DevBuf deepD, deepI, ceilD, ceilI;   // deep searches: one pass's lists, the next pass's ceilings
     // Smallest depth at which the margin rule sent most of a batch to the fp32 scan (storage 1): a few rows with a far
@@ -253,10 +256,20 @@ int add_device_rows(ipx_index* ix, const void* rows, int dtype, int64_t m, int64
         if (int rc = launch_pack_bf16(rows, dtype, m, m, ix->d, ix->Xh, row0, ipx::HBD, ix->nks_h, 1, st)) return rc;
         // the margin rule's corpus-side numbers: max |x|_2 of the values the exact score is defined on
         // (the fp32 rows in storage 1, the stored bf16 rows in storage 2) and max |x - bf16(x)|_2
+        ipx::OutlierState* outl = ix->storage == 1 ? (ipx::OutlierState*)ix->outl.p : nullptr;
+        if (outl && !ix->outl_thr_set) {
+            hipLaunchKernelGGL(ipx::outlier_threshold_kernel, dim3(1), dim3(1024), 0, st, rows, dtype, m, ix->d, outl);
+            IPX_HIP(hipGetLastError());
+            ix->outl_thr_set = true;
+        }
         const int blocks = (int)std::min<int64_t>((m + 3) / 4, 4096);
         hipLaunchKernelGGL(ipx::row_sumsq_max_kernel, dim3(blocks), dim3(256), 0, st, rows, dtype, m, ix->d,
-                           (uint32_t*)ix->maxsq.p, ix->storage);
+                           (uint32_t*)ix->maxsq.p, ix->storage, outl, row0);
         IPX_HIP(hipGetLastError());
+        if (outl) {      // listed rows never become candidates of the bf16 scan: their copies turn into NaN
+            hipLaunchKernelGGL(ipx::nan_rows_bf16_kernel, dim3(ipx::OUTLIER_MAX), dim3(64), 0, st, ix->Xh, ix->nks_h, outl);
+            IPX_HIP(hipGetLastError());
+        }
     }
     return 0;
 }
@@ -270,6 +283,10 @@ int grow_storage(ipx_index* ix, int64_t n, hipStream_t st) {
         if (!ix->maxsq.p) {
             if (int rc = ix->maxsq.ensure(256)) return rc;
             IPX_HIP(hipMemsetAsync(ix->maxsq.p, 0, 256, st));
+        }
+        if (ix->storage == 1 && !ix->outl.p) {
+            if (int rc = ix->outl.ensure(sizeof(ipx::OutlierState))) return rc;
+            IPX_HIP(hipMemsetAsync(ix->outl.p, 0, sizeof(ipx::OutlierState), st));
         }
     }
     return 0;
@@ -633,7 +650,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     if (int rc = ix->err.ensure(256)) return rc;
     if (int rc = ix->candD.ensure(ncand * sizeof(float))) return rc;
     if (int rc = ix->candI.ensure(ncand * sizeof(int64_t))) return rc;
-    if (int rc = ix->flags.ensure((size_t)(nq + 1) * sizeof(int))) return rc;      // + the error word (rescore_kernel)
+    if (int rc = ix->flags.ensure((size_t)(nq + 2) * sizeof(int))) return rc;      // + the error word, the outlier count
     if (S > 1) {
         if (int rc = ix->partD.ensure(ncand * S * sizeof(float))) return rc;
         if (int rc = ix->partI.ensure(ncand * S * sizeof(int64_t))) return rc;
@@ -755,6 +772,8 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     rp.outI = dI;
     rp.flags = (int*)ix->flags.p;
     rp.err = (const int*)ix->err.p;
+    rp.outl_count = ix->outl.p ? &((const ipx::OutlierState*)ix->outl.p)->count : nullptr;
+    rp.shared_list = 0;
     rp.nq = (int)nq;
     rp.id_base = ix->id_base;
     rp.acc_coef = margin_acc_coef(ix->nks_h * ipx::HBK, qparts);
@@ -782,18 +801,19 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
 
     // which queries failed the margin check? (the one host round trip of a pass: the flags and, behind them, the
     // scan's error word, which the rescoring kernel copies there — one copy into pinned memory, one wait)
-    if (ix->hflags_n < (size_t)nq + 1) {
+    if (ix->hflags_n < (size_t)nq + 2) {
         if (ix->hflags) (void)hipHostFree(ix->hflags);
         ix->hflags = nullptr;
         ix->hflags_n = 0;
-        const size_t want = std::max<size_t>((size_t)nq + 1, 4096);
+        const size_t want = std::max<size_t>((size_t)nq + 2, 4096);
         hipError_t e = hipHostMalloc((void**)&ix->hflags, want * sizeof(int), hipHostMallocDefault);
         if (e != hipSuccess) { ix->hflags = nullptr; return fail(IPX_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
         ix->hflags_n = want;
     }
     const int* flags = ix->hflags;
-    IPX_HIP(hipMemcpyAsync(ix->hflags, ix->flags.p, (size_t)(nq + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+    IPX_HIP(hipMemcpyAsync(ix->hflags, ix->flags.p, (size_t)(nq + 2) * sizeof(int), hipMemcpyDeviceToHost, st));
     IPX_HIP(hipStreamSynchronize(st));
+    ix->n_outliers = std::min(flags[nq + 1], ipx::OUTLIER_MAX);
     if (flags[nq]) {
         (void)hipMemsetAsync(ix->err.p, 0, 256, st);
         return fail(IPX_ERR_STATE, "search: candidate queue overflow (internal invariant violated)");
@@ -860,6 +880,8 @@ int exact_rows_path(ipx_index* ix, const float* qf, const std::vector<int>& sel,
     rp.outI = (int64_t*)ix->partI.p;
     rp.flags = (int*)ix->deepD.p;
     rp.err = nullptr;
+    rp.outl_count = nullptr;
+    rp.shared_list = 0;
     rp.nq = 0;
     rp.id_base = ix->id_base;
     rp.acc_coef = 1.f;
@@ -884,6 +906,57 @@ int exact_rows_path(ipx_index* ix, const float* qf, const std::vector<int>& sel,
                            dD + (size_t)f * k, dI + (size_t)f * k, (const int*)nullptr, (int64_t)0);
         IPX_HIP(hipGetLastError());
     }
+    return 0;
+}
+
+// The outlier rows (row_sumsq_max_kernel) never appear in a bf16 pass's result: every query scores them exactly on
+// the side (the rescoring kernel over the one shared list) and the two sorted lists are merged — (score desc, id asc),
+// the order of every other merge. Queries that go on to the fp32 scan afterwards have these rows of dD / dI rewritten.
+int merge_outlier_rows(ipx_index* ix, const float* qf, int64_t nq, int k, float* dD, int64_t* dI, hipStream_t st) {
+    const size_t n = (size_t)nq * k;
+    if (int rc = ix->olist.ensure(ipx::OUTLIER_MAX * sizeof(int64_t))) return rc;
+    if (int rc = ix->sideD.ensure(2 * n * sizeof(float))) return rc;
+    if (int rc = ix->sideI.ensure(2 * n * sizeof(int64_t))) return rc;
+    hipLaunchKernelGGL(ipx::outlier_list_kernel, dim3(1), dim3(256), 0, st, (const ipx::OutlierState*)ix->outl.p,
+                       ix->id_base, (int64_t*)ix->olist.p);
+    IPX_HIP(hipGetLastError());
+    IPX_HIP(hipMemcpyAsync(ix->sideD.p, dD, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    IPX_HIP(hipMemcpyAsync(ix->sideI.p, dI, n * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    ipx::RescoreParams rp;
+    rp.candD = nullptr;                      // a shared list is never cut: its approximate scores are not read
+    rp.candI = (const int64_t*)ix->olist.p;
+    rp.q = qf;
+    rp.qmap = nullptr;
+    rp.shared_list = 1;
+    rp.x_is_bf16 = 0;
+    rp.X = (const void*)ix->Xp;
+    rp.nks = ix->nks;
+    rp.maxsq = (const uint32_t*)ix->maxsq.p;
+    rp.outD = (float*)ix->sideD.p + n;
+    rp.outI = (int64_t*)ix->sideI.p + n;
+    rp.flags = (int*)ix->flags.p;            // the pass's flags are on the host already
+    rp.err = nullptr;
+    rp.outl_count = nullptr;
+    rp.nq = (int)nq;
+    rp.id_base = ix->id_base;
+    rp.acc_coef = 1.f;
+    rp.qparts = 1;
+    rp.d = ix->d;
+    rp.k = k;
+    rp.kc = ipx::OUTLIER_MAX;
+    rp.P = ipx::OUTLIER_MAX;
+    const int rlds = ((rp.nks * 16 * 4 + 15) & ~15) + rp.P * 8 + 4 * ipx::RS_KB * 16 * ipx::RS_ROW;
+    if (rlds > 64 * 1024)
+        IPX_HIP(hipFuncSetAttribute((const void*)ipx::rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rlds));
+    hipLaunchKernelGGL(ipx::rescore_kernel, dim3((unsigned)nq), dim3(256), rlds, st, rp);
+    IPX_HIP(hipGetLastError());
+    const int P = next_pow2(k), mlds = P * 24;
+    if (mlds > 64 * 1024)
+        IPX_HIP(hipFuncSetAttribute((const void*)ipx::merge_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mlds));
+    hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st, (const float*)ix->sideD.p,
+                       (const int64_t*)ix->sideI.p, 2, nq, k, k, P, 1, (int64_t)n, (int64_t)k, dD, dI, (const int*)nullptr,
+                       (int64_t)0);
+    IPX_HIP(hipGetLastError());
     return 0;
 }
 
@@ -949,6 +1022,8 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
         for (int& i : still) i = flagged[(size_t)i];
         flagged.swap(still);
     }
+    if (ix->storage == 1 && ix->n_outliers > 0)
+        if (int rc = merge_outlier_rows(ix, qf, nq, k, dD, dI, st)) return rc;
     if (flagged.empty()) return 0;
     if (ix->storage != 1) return exact_rows_path(ix, qf, flagged, k, dD, dI, st);
     return redo_queries(ix, qf, flagged, k, dD, dI, st, [&](const float* q2, int64_t n2, float* D2, int64_t* I2) {
@@ -1152,7 +1227,7 @@ int ipx_destroy(ipx_index* ix) {
     if (ix->Xp) (void)hipFree(ix->Xp);
     if (ix->Xh) (void)hipFree(ix->Xh);
     for (DevBuf* b : {&ix->Qp, &ix->cand, &ix->partD, &ix->partI, &ix->err, &ix->stageIn, &ix->stageQ, &ix->stageW,
-                      &ix->outD, &ix->outI, &ix->trace, &ix->pub, &ix->maxsq, &ix->qfused, &ix->candD, &ix->candI, &ix->deepD, &ix->deepI, &ix->ceilD, &ix->ceilI,
+                      &ix->outD, &ix->outI, &ix->trace, &ix->pub, &ix->maxsq, &ix->outl, &ix->olist, &ix->sideD, &ix->sideI, &ix->qfused, &ix->candD, &ix->candI, &ix->deepD, &ix->deepI, &ix->ceilD, &ix->ceilI,
                       &ix->flags, &ix->sel, &ix->qsel, &ix->selD, &ix->selI, &ix->poolH, &ix->poolW, &ix->poolQ})
         b->release();
     for (auto& e : ix->ev)
@@ -1636,6 +1711,8 @@ int ipx_last_bf16_stats(ipx_index* ix, float* rescore_ms, int* candidates, int64
     if (fallback_queries) *fallback_queries = ix->last_fallback;
     return 0;
 }
+
+int ipx_outlier_rows(const ipx_index* ix) { return ix ? ix->n_outliers : 0; }
 
 int ipx_last_geometry(const ipx_index* ix, int* workgroups, int* splits, int* queue_cap) {
     if (!ix) return fail(IPX_ERR_ARG, "last_geometry: null index");

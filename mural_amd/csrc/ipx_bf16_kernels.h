@@ -157,11 +157,58 @@ pack_rows_bf16_kernel(const void* __restrict__ src, int dtype, int64_t n, int64_
 //   maxsq[1] = max over rows of |x - bf16(x)|^2, the ACTUAL rounding error of the scanned copy
 //              (mode 1; 0 in mode 2, where the scanned rows are the exact ones).
 // One wave per row, grid-stride.
+//
+// Outlier rows (index with fp32 rows + bf16 copy only). Both numbers are maxima over the whole index, so a handful of
+// rows far longer than the rest — or one NaN / inf row — would widen every query's margin. Rows whose |x|^2 is not
+// <= *thr2 (4 x the mean |x|^2 of the first rows added: twice their rms norm; NaN and inf included) are therefore
+// taken out of the bf16 scan altogether: their ids go to a short list (at most OUTLIER_MAX; rows beyond that count as
+// ordinary rows), they do not enter the maxima, nan_rows_bf16_kernel turns their bf16 copies into NaN (a NaN score is
+// never above a threshold, so they are never candidates), and every search scores them exactly on the side and merges
+// them in (scan_bf16_path). The margin rule then speaks about the remaining rows only, which is all its proof needs.
+constexpr int OUTLIER_MAX = 256;
+struct OutlierState {          // device memory
+    float thr2;                // 0 = not set yet
+    int count;                 // rows classified (may exceed OUTLIER_MAX: only the first OUTLIER_MAX are listed)
+    int64_t pad;
+    int64_t rows[OUTLIER_MAX]; // row numbers in the index, in no particular order
+};
+
+// thr2 = 4 x mean |x|^2 over the first min(n, 2048) rows of the first add (one workgroup of 1024; set once)
+__global__ void __launch_bounds__(1024)
+outlier_threshold_kernel(const void* __restrict__ src, int dtype, int64_t n, int d, OutlierState* st) {
+    __shared__ double part[1024];
+    const int64_t m = n < 2048 ? n : 2048;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < m * d; i += 1024) {
+        const float x = load_as_f32(src, dtype, i);
+        if (x <= FLT_MAX && x >= -FLT_MAX) acc += (double)x * (double)x;      // NaN / inf do not set the scale
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 512; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = part[0] / (double)m;
+        st->thr2 = mean > 0.0 && mean < 1e37 ? (float)(4.0 * mean) : FLT_MAX;
+    }
+}
+
+// the list the side rescoring reads: id_base + row, -1 behind the last one
 __global__ void __launch_bounds__(256)
-row_sumsq_max_kernel(const void* __restrict__ src, int dtype, int64_t n, int d, uint32_t* __restrict__ maxsq, int mode) {
+outlier_list_kernel(const OutlierState* __restrict__ st, int64_t id_base, int64_t* __restrict__ ids) {
+    const int cnt = st->count < OUTLIER_MAX ? st->count : OUTLIER_MAX;
+    for (int i = threadIdx.x; i < OUTLIER_MAX; i += 256) ids[i] = i < cnt ? id_base + st->rows[i] : -1;
+}
+
+__global__ void __launch_bounds__(256)
+row_sumsq_max_kernel(const void* __restrict__ src, int dtype, int64_t n, int d, uint32_t* __restrict__ maxsq, int mode,
+                     OutlierState* outl, int64_t row0) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const float thr2 = outl ? outl->thr2 : 0.f;
     float best = 0.f, dbest = 0.f;
     bool bad = false;
     for (int64_t r = wave; r < n; r += nwaves) {
@@ -176,6 +223,15 @@ row_sumsq_max_kernel(const void* __restrict__ src, int dtype, int64_t n, int d, 
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); ds += __shfl_xor(ds, off); }
+        if (thr2 > 0.f && !(s <= thr2)) {            // wave-uniform: an outlier row (or NaN / inf)
+            int pos = 0;
+            if (lane == 0) pos = atomicAdd(&outl->count, 1);
+            pos = __shfl(pos, 0);
+            if (pos < OUTLIER_MAX) {
+                if (lane == 0) outl->rows[pos] = row0 + r;
+                continue;                            // listed: it does not enter the maxima
+            }
+        }
         if (!(s <= FLT_MAX) || !(ds <= FLT_MAX)) bad = true;      // NaN or inf
         best = fmaxf(best, s);
         dbest = fmaxf(dbest, ds);
@@ -183,6 +239,20 @@ row_sumsq_max_kernel(const void* __restrict__ src, int dtype, int64_t n, int d, 
     if (lane == 0) {
         atomicMax(maxsq, bad ? 0x7fc00000u : __float_as_uint(best));
         if (mode != 2) atomicMax(maxsq + 1, bad ? 0x7fc00000u : __float_as_uint(dbest));
+    }
+}
+
+// bf16 copies of the listed outlier rows -> NaN (every listed row, every time: idempotent). One workgroup per row.
+__global__ void __launch_bounds__(64)
+nan_rows_bf16_kernel(uint16_t* __restrict__ Xh, int nks, const OutlierState* __restrict__ outl) {
+    const int cnt = outl->count < OUTLIER_MAX ? outl->count : OUTLIER_MAX;
+    if ((int)blockIdx.x >= cnt) return;
+    const int64_t row = outl->rows[blockIdx.x];
+    const int64_t tile = row / HBD;
+    const int rr = (int)(row - tile * HBD);
+    for (int i = threadIdx.x; i < nks * 32; i += 64) {           // 32 bf16 per K-stage line
+        const int ks = i >> 5, e = i & 31;
+        Xh[((tile * nks + ks) * HBD + rr) * 32 + e] = 0x7fc0;
     }
 }
 
@@ -663,12 +733,14 @@ struct RescoreParams {
     const int64_t* candI;    // [nq][kc] id_base + row, -1 = empty (at the end)
     const float* q;          // [nq][d] fp32 queries, row-major
     const int* qmap;         // optional: list qi belongs to query qmap[qi] (exact_rows_path: many lists, one query)
+    int shared_list;         // 1: every query rescoring the same list candD / candI [kc] (the outlier rows)
     const void* X;           // packed corpus: fp32 (tiles of 128) or bf16 (tiles of 256)
     const uint32_t* maxsq;   // float bits of max_x |x|^2 and max_x |x - bf16(x)|^2
     float* outD;             // [nq][k]
     int64_t* outI;           // [nq][k]
     int* flags;              // [nq] (+ 1 when err is given)
     const int* err;          // optional: the scan's error word, copied to flags[nq] so that one readback brings both
+    const int* outl_count;   // optional (with err): the index's outlier-row count, copied to flags[nq + 1]
     int nq;                  // queries of the pass (position of that copy)
     int64_t id_base;
     float acc_coef;          // accumulation-error coefficient (host: margin_acc_coef)
@@ -712,15 +784,17 @@ rescore_kernel(const RescoreParams p) {
     const float Mx = sqrtf(__uint_as_float(p.maxsq[0])), Dx = sqrtf(__uint_as_float(p.maxsq[1]));
     const float eps = 1.002f * ((qn + dqn) * Dx + dqn * Mx) + p.acc_coef * (qn + dqn) * (Mx + Dx);
 
-    const float* cD = p.candD + qi * (int64_t)p.kc;
-    const int64_t* cI = p.candI + qi * (int64_t)p.kc;
+    const float* cD = p.candD + (p.shared_list ? 0 : qi * (int64_t)p.kc);
+    const int64_t* cI = p.candI + (p.shared_list ? 0 : qi * (int64_t)p.kc);
     if (tid == 0) {
         // candidates are sorted: valid ones first. binary search the count, then the margin cut.
         int lo = 0, hi = p.kc;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (cI[mid] >= 0) lo = mid + 1; else hi = mid; }
         const int nvalid = lo;
         int m = nvalid, flag = 0;
-        if (eps == 0.f) {
+        if (p.shared_list) {
+            // the outlier rows: every listed row is scored, nothing was cut off
+        } else if (eps == 0.f) {
             // a zero query (or an all-zero index): every approximate score IS the exact score, the list is in the
             // result order (score desc, id asc) already — its first k entries are the answer, whatever ties follow
             m = nvalid < p.k ? nvalid : p.k;
@@ -736,7 +810,10 @@ rescore_kernel(const RescoreParams p) {
         }
         s_m = m;
         p.flags[qi] = flag;
-        if (p.err && qi == 0) p.flags[p.nq] = *p.err;      // the scans are done: same stream
+        if (p.err && qi == 0) {                            // the scans are done: same stream
+            p.flags[p.nq] = *p.err;
+            p.flags[p.nq + 1] = p.outl_count ? *p.outl_count : 0;
+        }
     }
     __syncthreads();
     const int m = s_m;

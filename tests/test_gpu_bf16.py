@@ -279,6 +279,114 @@ def test_margin_rule_against_coherent_rounding_errors(R):
     assert_bits(D, I, Q, X, k)
 
 
+def _with_outliers(X, rows, rng, special=True):
+    X = X.copy()
+    for j, r in enumerate(rows):
+        X[r] *= np.float32(3.0 + (j % 7))                     # 3x .. 9x the ordinary norm
+    if special and len(rows) >= 4:
+        X[rows[0], 1] = np.nan
+        X[rows[1], 0] = np.inf
+        X[rows[2], 2] = -np.inf
+        X[rows[3]] *= np.float32(1e30)                        # products overflow to +-inf
+    return X
+
+
+@pytest.mark.parametrize("n,d,nq,k,adds,nout", [
+    (30000, 768, 300, 100, 1, 12),     # a few long rows + NaN / inf rows, large batch (16-wave kernel)
+    (30000, 768, 32, 100, 3, 12),      # small batch (64-query tile, hi + lo parts), outliers arrive over three adds
+    (20000, 100, 513, 10, 2, 40),
+    (50000, 64, 70, 1000, 1, 9),       # deep lists
+    (9000, 48, 64, 1500, 1, 9),        # deeper than the bf16 scan serves: the fp32 scan sees the rows itself
+    (20000, 96, 260, 50, 4, 300),      # more outliers than the side list holds: the rest count as ordinary rows
+    (600, 32, 5, 700, 1, 20),          # k > n
+])
+def test_outlier_rows_are_scored_on_the_side(R, n, d, nq, k, adds, nout):
+    """Storage 1: rows far longer than the rest (and NaN / inf rows) stay out of the bf16 scan and of the margin rule's
+    norm bounds; every search scores them exactly and merges them in. Same bits as the oracle and as the fp32 scan,
+    and — the point — no query is sent to the repeat pass or the fp32 scan because of them."""
+    rng = np.random.default_rng(77)
+    rows = np.sort(rng.choice(np.arange(2100, n) if n > 4000 else np.arange(n // 2, n), size=nout, replace=False))
+    X = _with_outliers(gaussian(1234, (n, d)), rows, rng)
+    Q = gaussian(4321, (nq, d))
+    Q[0] = 0                                                  # a zero query: NaN scores for the inf rows
+    ix = index(R, X, "bf16scan", adds)
+    base = 1000
+    ix.set_id_base(base)
+    D, I = ix.search(Q, k)
+    with np.errstate(all="ignore"):
+        rD, rI = O.topk_total_order(O.scores_mfma_order(Q, X), k, id_base=base)
+    assert np.array_equal(I, rI), f"ids differ at {np.argwhere(I != rI)[:3].tolist()}"
+    assert np.array_equal(D.view(np.uint32), rD.view(np.uint32)), "score bits differ"
+    st = ix.last_bf16_stats()
+    if 2 * k <= 2048 and n > 4000:      # (the small index takes its scale from rows that include the long ones)
+        assert st["candidates"] > 0 and st["outlier_rows"] == min(nout, 256)
+        if nout <= 256 and k <= 100:
+            assert st["fallback_queries"] == 0
+    ix.set_param("f32_scan", 1)
+    D2, I2 = ix.search(Q, k)
+    assert np.array_equal(I, I2) and np.array_equal(D.view(np.uint32), D2.view(np.uint32))
+    ix.set_param("f32_scan", 0)
+    # every large-batch scan kernel skips the NaN copies the same way
+    if nq > 64 and 2 * k <= 2048:
+        for prm in ({"bf16_waves": 8}, {"bf16_pp": 1}, {"bf16_pp": 3}, {"bf16_shape16": 0}, {"query_parts": 2},
+                    {"no_small_batch": 1, "max_splits": 1}):
+            for key, val in prm.items():
+                ix.set_param(key, val)
+            D3, I3 = ix.search(Q, k)
+            assert ix.last_bf16_stats()["candidates"] > 0
+            assert np.array_equal(I, I3) and np.array_equal(D.view(np.uint32), D3.view(np.uint32)), prm
+            for key in prm:
+                ix.set_param(key, {"bf16_shape16": 1}.get(key, 0))
+
+
+def test_index_remembers_a_depth_the_bf16_scan_cannot_serve(R):
+    """More long rows than the side list holds: the rest widen every margin, a deep search fails its checks for most
+    of the batch, goes to the fp32 scan — and the next search at that depth goes there directly; shallower searches
+    and a grown index try the bf16 scan again."""
+    n, d, nq, k = 20000, 96, 128, 700
+    rng = np.random.default_rng(3)
+    X = gaussian(8, (n, d))
+    X[rng.choice(np.arange(3000, n), size=400, replace=False)] *= np.float32(30.0)
+    Q = gaussian(9, (nq, d))
+    ix = index(R, X, "bf16scan")
+    rD, rI = O.topk_total_order(O.scores_mfma_order(Q, X), k)
+    D, I = ix.search(Q, k)
+    st = ix.last_bf16_stats()
+    assert st["outlier_rows"] == 256 and st["candidates"] > 0 and st["fallback_queries"] > nq // 2
+    assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
+    D, I = ix.search(Q, k)
+    assert ix.last_bf16_stats()["candidates"] == 0            # straight to the fp32 scan
+    assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
+    D, I = ix.search(Q, 10)
+    assert ix.last_bf16_stats()["candidates"] > 0             # shallower: the bf16 scan again
+    assert np.array_equal(I, rI[:, :10]) and np.array_equal(D.view(np.uint32), rD[:, :10].view(np.uint32))
+    ix.add(gaussian(10, (100, d)))
+    ix.search(Q, k)
+    assert ix.last_bf16_stats()["candidates"] > 0             # new rows: the memory is cleared
+
+
+def test_outlier_threshold_comes_from_the_first_rows(R):
+    """The scale is set by the first rows added; an index whose first rows are all zero (or NaN) lists only NaN / inf
+    rows; an index of uniformly long rows lists none."""
+    n, d, nq, k = 8000, 64, 100, 20
+    Q = gaussian(5, (nq, d))
+    X = gaussian(6, (n, d)) * np.float32(50.0)                # long, but uniformly so
+    ix = index(R, X, "bf16scan", 2)
+    D, I = ix.search(Q, k)
+    assert ix.last_bf16_stats()["outlier_rows"] == 0
+    assert_bits(D, I, Q, X, k)
+    X = gaussian(6, (n, d))
+    X[:3000] = 0
+    X[10, 0] = np.nan
+    X[5000, 3] = np.inf
+    ix = index(R, X, "bf16scan", 1)
+    D, I = ix.search(Q, k)
+    assert ix.last_bf16_stats()["outlier_rows"] == 2
+    with np.errstate(all="ignore"):
+        rD, rI = O.topk_total_order(O.scores_mfma_order(Q, X), k)
+    assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
+
+
 @pytest.mark.parametrize("storage", ["bf16scan", "bf16"])
 @pytest.mark.parametrize("nq", [32, 300])
 def test_short_rows_many_runs_per_workgroup(R, storage, nq):

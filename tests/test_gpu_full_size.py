@@ -77,18 +77,10 @@ def test_headline_corpus_8p8m_fp32(R):
     assert torch.equal(Ik[:, :100], I) and torch.equal(Dk[:, :100].contiguous().view(torch.int32), D.view(torch.int32))
     ix.set_param("f32_scan", 0)
     Dk2, Ik2 = ix.search_device(Q, 1000)
-    # (the planted rows have 3x the norm of the others: they set the margin rule's corpus-wide bound, and at this
-    #  depth every query then goes on to the repeat pass / the fp32 scan — the bits must not depend on the route;
-    #  without plants scripts/depth_sweep.py measures 0 repeats at k = 1000)
-    assert ix.last_bf16_stats()["candidates"] == 3000 and ix.last_bf16_stats()["fallback_queries"] == nq
-    # ... and the index remembers: the next search at this depth goes to the fp32 scan directly (no wasted bf16
-    # passes), shallower ones stay on the bf16 scan
-    Dk3, Ik3 = ix.search_device(Q, 1000)
-    assert ix.last_bf16_stats()["candidates"] == 0
-    assert torch.equal(Ik, Ik3) and torch.equal(Dk.view(torch.int32), Dk3.view(torch.int32))
-    D2c, I2c = ix.search_device(Q, 100)
-    assert ix.last_bf16_stats()["candidates"] > 0 and torch.equal(I, I2c)
-    del Dk3, Ik3, D2c, I2c
+    # (the planted rows have 3x the norm of the others: the index keeps them out of the bf16 scan and of the margin
+    #  rule's norm bounds and scores them on the side — without that every query would go on to the fp32 scan here)
+    st = ix.last_bf16_stats()
+    assert st["candidates"] == 3000 and st["outlier_rows"] == plant_q.numel() and st["fallback_queries"] <= nq // 100
     assert torch.equal(Ik, Ik2) and torch.equal(Dk.view(torch.int32), Dk2.view(torch.int32))
     del Dk, Ik, Dk2, Ik2
     # (3) small batches on the fp32 rows (scan_f32_small_kernel) and on the bf16 copy: the same bits again,
