@@ -40,8 +40,18 @@ for c in range(cases):
         X = rng.integers(-2, 3, (n, d)).astype(np.float32)
     else:
         X = np.zeros((n, d), np.float32); X[:, 0] = np.arange(n, dtype=np.float32) * (1 if rng.random() < 0.5 else -1)
-    Q = rng.integers(-2, 3, (nq, d)).astype(np.float32) if kind == "quant" else rng.standard_normal((nq, d), dtype=np.float32)
     storage = str(rng.choice(["f32", "bf16scan", "bf16"]))
+    if rng.random() < 0.3:
+        # a few rows far longer than the rest; NaN / inf rows where fp32 rows are kept (an index of bf16 rows only
+        # answers those by the exact pass over every row: slow on the long scans)
+        m = int(rng.choice([1, 3, 40, 300]))
+        rows = rng.integers(0, n, m)
+        X[rows] *= rng.choice([3.0, 10.0, 1e4, 1e30], size=(m, 1)).astype(np.float32)
+        if storage != "bf16":
+            for r, v in zip(rng.integers(0, n, 3), (np.nan, np.inf, -np.inf)):
+                if rng.random() < 0.5:
+                    X[r, int(rng.integers(0, d))] = v
+    Q = rng.integers(-2, 3, (nq, d)).astype(np.float32) if kind == "quant" else rng.standard_normal((nq, d), dtype=np.float32)
     if storage == "bf16" and k > 1638:
         k = 1638
     ms = int(rng.choice([0, 0, 1, 2, 5, 40]))
@@ -55,7 +65,8 @@ for c in range(cases):
         how = rng.choice(["f32", "f16", "torch_f32", "torch_bf16"])
         part = X[lo:lo + step]
         if how == "f16":                                  # float16 shards are widened on the device
-            h = np.clip(part, -60000, 60000).astype(np.float16)
+            with np.errstate(all="ignore"):
+                h = np.clip(part, -60000, 60000).astype(np.float16)
             X[lo:lo + step] = h.astype(np.float32)
             ix.add(h)
         elif how == "torch_f32":
@@ -69,7 +80,8 @@ for c in range(cases):
     assert ix.ntotal == n
     ix.set_param("max_splits", ms)
     Xe = bf16_round(X) if storage == "bf16" else X
-    rD, rI = O.topk_total_order(O.scores_mfma_order(Q, Xe), k)
+    with np.errstate(all="ignore"):
+        rD, rI = O.topk_total_order(O.scores_mfma_order(Q, Xe), k)
     variants = [("default", {})]
     if storage != "bf16":
         variants += [("f32 large", {"f32_scan": 1, "no_small_batch": 1}), ("f32 small", {"f32_scan": 1, "small_f32_limit": 100000})]
