@@ -24,6 +24,8 @@ for kv in filter(None, os.environ.get("PARAMS", "").split(",")):      # e.g. PAR
     ix.set_param(name, int(val))
 for nq in [int(x) for x in os.environ.get("NQ", "1,4,16,32,64,65,128,256").split(",")]:
     Q = torch.randn((nq, d), generator=g, device=dev)
+    if os.environ.get("QNAN") == "1":      # diagnostic: no score is ever admitted (the scan's floor without appends)
+        Q[:, 0] = float("nan")
     for _ in range(2):
         ix.search_device(Q, k)
     torch.cuda.synchronize()
