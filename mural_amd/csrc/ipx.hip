@@ -1002,7 +1002,10 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     int qparts = ix->query_parts > 0 ? ix->query_parts : ((small || !one_part_fits) ? 2 : 1);
     int kc = ix->force_kc > 0 ? ix->force_kc
              : qparts == 1 ? std::max(256, ix->storage == 2 ? mult1 * k : std::min(mult1 * k, std::max(2048, 3 * k)))
-             : ix->storage == 2 ? std::max(256, k + k / 4)
+             // two parts, bf16 rows only (no row rounding in the margin): 1.25k candidates; small batches 1.5k and
+             // as few as 128 — a list shorter than the number of splits makes the splits' published bests a far
+             // tighter bound (scan_bf16_kernel: the kc-th largest of them instead of the minimum)
+             : ix->storage == 2 ? (small ? std::max(128, k + k / 2) : std::max(256, k + k / 4))
              // two parts, fp32 rows: 2k candidates, 3k for shallow lists (measured, small batches: at k = 150 a
              // list of 300 left 2 of 32 queries to the repeat pass, 450 none; from k = 250 on 2k leaves none);
              // 256 (the number of splits: every split publishes just its best score) while that is >= 2.5k

@@ -410,7 +410,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
     // Small batches with short lists (candidates <= 4 S): no compaction episodes unless a queue fills.
     // Each split deals its tiles round-robin to r = ceil(candidates / S) sub-splits and keeps the best
     // score of each by an LDS max beside the appends; the S r bests are published / polled at r, 2r,
-    // 4r, ... tiles and every 32, and their minimum bounds the list's last score from below (S r
+    // 4r, ... tiles and every 64, and their minimum bounds the list's last score from below (S r
     // disjoint sets of rows, each holding a row at or above it). With r == 1: every split publishes
     // its best. (Each split sees only N / S rows, so its own k-th best is a poor threshold anyway;
     // the union bound is the one that prunes.)
@@ -615,8 +615,8 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
         if (p.trace) { tr_e1 = __builtin_readcyclecounter(); tr_epi += tr_e1 - tr_e0; }
         if constexpr (QW == 1) {
             const int rounds = tiles_done / rs;                    // completed rounds over the sub-splits
-            if (fast1 && tiles_done == rounds * rs && ((rounds & (rounds - 1)) == 0 || (tiles_done & 31) == 0)) {
-                // publish the sub-splits' bests, take the minimum over all splits as the new floor.
+            if (fast1 && tiles_done == rounds * rs && ((rounds & (rounds - 1)) == 0 || (tiles_done & 63) == 0)) {
+                // publish the sub-splits' bests, take a bound from every split's values as the new floor.
                 // After the first round every split is at the same point: wait (bounded) until all of
                 // them have published, so the next tile already runs against a bound.
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -625,8 +625,45 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
                     const uint32_t b = best[e];
                     if (b) __hip_atomic_store(mypub + e, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                const int q = tid & (BQ_ - 1), part = tid / BQ_;           // 8 threads per query
                 const int nvals = p.S * rs;
+                if (nvals <= 256) {
+                    // K = min(candidates, values): the K-th largest of the published bests. They come from disjoint
+                    // sets of rows, so at least K rows score at or above it (with K = every value this is the minimum;
+                    // with a list shorter than the number of splits it is far tighter: 125 candidates over 256 splits
+                    // admit ~ 170 / N of the rows instead of ~ 1400 / N). Eight adjacent lanes per query hold the
+                    // values in registers and select bit by bit over the top 18 bits (a bound rounded down is still
+                    // a bound); unpublished values are 0 and never count.
+                    const int q = tid >> 3, part = tid & 7;
+                    const int K = p.k < nvals ? p.k : nvals;
+                    const uint32_t* col = p.pub + (size_t)qb * nvals * BQ_ + q;
+                    for (int attempt = 0; attempt < (rounds == 1 ? 64 : 1); ++attempt) {
+                        uint32_t vals[32];
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) {
+                            const int s2 = part + 8 * i;
+                            vals[i] = s2 < nvals ? __hip_atomic_load(col + (size_t)s2 * BQ_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                        }
+                        uint32_t pre = 0;
+#pragma unroll 1
+                        for (int b = 31; b >= 14; --b) {
+                            const uint32_t cand = pre | (1u << b);
+                            int c = 0;
+#pragma unroll
+                            for (int i = 0; i < 32; ++i) c += vals[i] >= cand ? 1 : 0;
+                            c += __shfl_xor(c, 1);
+                            c += __shfl_xor(c, 2);
+                            c += __shfl_xor(c, 4);
+                            if (c >= K) pre = cand;
+                        }
+                        if (part == 0) tmin[q] = pre;
+                        __syncthreads();
+                        // queries beyond nq never publish: they do not count as "missing"
+                        const bool missing = tid < BQ_ && (int64_t)qb * BQ_ + tid < p.nq && tmin[tid] == 0;
+                        if (!__syncthreads_or(missing)) break;
+                        __builtin_amdgcn_s_sleep(20);
+                    }
+                } else {
+                const int q = tid & (BQ_ - 1), part = tid / BQ_;           // 8 threads per query: the minimum
                 const int per = (nvals + 7) / 8;
                 const int s_lo = part * per, s_hi = s_lo + per < nvals ? s_lo + per : nvals;
                 const uint32_t* col = p.pub + (size_t)qb * nvals * BQ_ + q;
@@ -645,6 +682,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
                     const bool missing = tid < BQ_ && (int64_t)qb * BQ_ + tid < p.nq && tmin[tid] == 0;
                     if (!__syncthreads_or(missing)) break;
                     __builtin_amdgcn_s_sleep(20);
+                }
                 }
                 if (tid < BQ_) {
                     const uint32_t v = tmin[tid];

@@ -252,12 +252,32 @@ __device__ __forceinline__ void compact_query(const ScanParams& p, uint64_t* scr
     const int n = cnts[ql];
     // nothing to drop and nothing to publish: leave the queue as it is
     if (!final_pass && n <= p.k && !(pub_slot && n >= p.r)) return;
-    int P = 2;
-    while (P < n) P <<= 1;
-    for (int i = lane; i < P; i += 64) scratch[i] = (i < n) ? queue[i] : 0ull;
+    int P = 2, nkeep = n;
+    if (final_pass) {
+        // Only entries at or above the threshold can be in the result (it is this split's k-th best score or the
+        // union bound, whichever is larger; an entry equal to it may be the k-th best itself). Entries admitted
+        // early, against a weaker threshold, are dropped here: with many splits per query (small batches) a queue
+        // ends with hundreds of entries of which a handful count, and the sort below shrinks accordingly.
+        const uint32_t cut = f32_ordered(taus[ql]);
+        int base = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const uint64_t key = i < n ? queue[i] : 0ull;
+            const bool keep = i < n && (uint32_t)(key >> 32) >= cut;
+            const uint64_t mask = __ballot(keep);
+            if (keep) scratch[base + __popcll(mask & ((1ull << lane) - 1))] = key;
+            base += __popcll(mask);
+        }
+        nkeep = base;
+        while (P < nkeep) P <<= 1;
+        for (int i = nkeep + lane; i < P; i += 64) scratch[i] = 0ull;
+    } else {
+        while (P < n) P <<= 1;
+        for (int i = lane; i < P; i += 64) scratch[i] = (i < n) ? queue[i] : 0ull;
+    }
     wave_lds_sync();
     wave_sort_desc(scratch, P, lane);
-    const int m = n < p.k ? n : p.k;
+    const int m = nkeep < p.k ? nkeep : p.k;
     if (!final_pass) {
         for (int i = lane; i < m; i += 64) queue[i] = scratch[i];
         if (lane == 0) {
