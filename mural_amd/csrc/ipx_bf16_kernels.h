@@ -314,6 +314,42 @@ __device__ __forceinline__ void issue_stage_bf16(const ScanParams& p, char* buf,
     for (int i = 0; i < HCfg<QW, QP>::LOADS; ++i) sp.issue(i);
 }
 
+// Short-list path of the small-batch scans: the K-th largest of the nvals values published for one query (ordered
+// score bits, 0 = not published yet; stride elements apart), rounded down to its top 18 bits — 0 if fewer than K are
+// there. The values are the best scores of disjoint sets of rows, so at least K rows of the index score at or above
+// the result: a floor for a list of K candidates. (With K = nvals it is the minimum; with a list shorter than the
+// number of sets it is far tighter: 150 of 256 sets admit ~ 230 / N of the rows, the minimum ~ 1400 / N.) TPQ adjacent
+// lanes per query hold NV values each in registers and decide bit by bit; part = lane's index among the TPQ.
+template <int NV, int TPQ>
+__device__ __forceinline__ uint32_t kth_largest_published(const uint32_t* col, size_t stride, int nvals, int K, int part) {
+    uint32_t vals[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int s2 = part + TPQ * i;
+        vals[i] = s2 < nvals ? __hip_atomic_load(col + (size_t)s2 * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+    uint32_t pre = 0;
+#pragma unroll 1
+    for (int b = 31; b >= 14; --b) {
+        const uint32_t cand = pre | (1u << b);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) c += vals[i] >= cand ? 1 : 0;
+        if constexpr (TPQ == 8) {
+            // sum over the 8 lanes by DPP moves (a few cycles each; a shuffle through LDS costs ~100): the other lane
+            // of the pair, the other pair of the quad, the mirror lane of the half-row (= the other quad's sum)
+            c += __builtin_amdgcn_update_dpp(0, c, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+            c += __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+            c += __builtin_amdgcn_update_dpp(0, c, 0x141, 0xF, 0xF, true);      // row_half_mirror
+        } else {
+#pragma unroll
+            for (int off = 1; off < TPQ; off <<= 1) c += __shfl_xor(c, off);
+        }
+        if (c >= K) pre = cand;
+    }
+    return pre;
+}
+
 template <int BQ_>
 __device__ __forceinline__ void poll_union_threshold_n(const ScanParams& p, float* taus, int qb, int tid) {
     if (p.S <= 1) return;
@@ -627,35 +663,12 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
                 }
                 const int nvals = p.S * rs;
                 if (nvals <= 256) {
-                    // K = min(candidates, values): the K-th largest of the published bests. They come from disjoint
-                    // sets of rows, so at least K rows score at or above it (with K = every value this is the minimum;
-                    // with a list shorter than the number of splits it is far tighter: 125 candidates over 256 splits
-                    // admit ~ 170 / N of the rows instead of ~ 1400 / N). Eight adjacent lanes per query hold the
-                    // values in registers and select bit by bit over the top 18 bits (a bound rounded down is still
-                    // a bound); unpublished values are 0 and never count.
-                    const int q = tid >> 3, part = tid & 7;
+                    // the K-th largest of the published bests, K = min(candidates, values): 8 lanes per query
                     const int K = p.k < nvals ? p.k : nvals;
-                    const uint32_t* col = p.pub + (size_t)qb * nvals * BQ_ + q;
+                    const uint32_t* col = p.pub + (size_t)qb * nvals * BQ_ + (tid >> 3);
                     for (int attempt = 0; attempt < (rounds == 1 ? 64 : 1); ++attempt) {
-                        uint32_t vals[32];
-#pragma unroll
-                        for (int i = 0; i < 32; ++i) {
-                            const int s2 = part + 8 * i;
-                            vals[i] = s2 < nvals ? __hip_atomic_load(col + (size_t)s2 * BQ_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                        }
-                        uint32_t pre = 0;
-#pragma unroll 1
-                        for (int b = 31; b >= 14; --b) {
-                            const uint32_t cand = pre | (1u << b);
-                            int c = 0;
-#pragma unroll
-                            for (int i = 0; i < 32; ++i) c += vals[i] >= cand ? 1 : 0;
-                            c += __shfl_xor(c, 1);
-                            c += __shfl_xor(c, 2);
-                            c += __shfl_xor(c, 4);
-                            if (c >= K) pre = cand;
-                        }
-                        if (part == 0) tmin[q] = pre;
+                        const uint32_t pre = kth_largest_published<32, 8>(col, BQ_, nvals, K, tid & 7);
+                        if ((tid & 7) == 0) tmin[tid >> 3] = pre;
                         __syncthreads();
                         // queries beyond nq never publish: they do not count as "missing"
                         const bool missing = tid < BQ_ && (int64_t)qb * BQ_ + tid < p.nq && tmin[tid] == 0;
