@@ -267,7 +267,16 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int r15 = lane & 15, g4 = lane >> 4;
-            const uint32_t chunk = (uint32_t)((g4 ^ ((r15 >> 2) & 3)) * 16);
+            // Which 8 features a lane group multiplies is free as long as the corpus and the query operand agree
+            // (the MFMA sums over all 32): group g takes 16-byte chunk sigma(g) = (0, 3, 1, 2)[g] of the stage line.
+            // With sigma = identity every ds_read_b128 here was 2-way bank-conflicted (SQ_LDS_BANK_CONFLICT = one extra
+            // LDS cycle per 16 lanes, 512 cycles per stage and CU): the instruction is served in lane groups
+            // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), i.e. rows 0-3 and 12-15 of group g with rows 4-11 of
+            // group g + 1, and under the packed swizzle (chunk ^ (row >> 2 & 3)) rows 0-3 / 4-7 and 8-11 / 12-15 then
+            // landed on the same banks. sigma makes the four quads of rows of every lane group hit four different
+            // chunks.
+            const int sigma = (0x9C >> (2 * g4)) & 3;                 // 0, 3, 1, 2
+            const uint32_t chunk = (uint32_t)((sigma ^ ((r15 >> 2) & 3)) * 16);
             const uint32_t a16 = (wd * 64 + r15) * 64 + chunk;
             const uint32_t b16 = HSTAGE_A + (wq * 64 + r15) * 64 + chunk;
             f32x4 x0, x1, x2, x3;
