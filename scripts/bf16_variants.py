@@ -25,10 +25,15 @@ ix.reserve(rows)
 for b, lo in enumerate(range(0, rows, 200000)):
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + b)
-    ix.add(torch.randn((200000, 768), generator=g, device=dev)[: rows - lo])
+    blk = torch.randn((200000, 768), generator=g, device=dev)[: rows - lo]
+    if os.environ.get("ZERO") == "1":      # diagnostic: all-zero operands (the clock the chip holds without data toggling)
+        blk.zero_()
+    ix.add(blk)
 g = torch.Generator(device=dev)
 g.manual_seed(4321)
 Q = torch.randn((nq, 768), generator=g, device=dev)
+if os.environ.get("ZERO") == "1":
+    Q.zero_()
 ix.set_timing(True)
 
 # (name, params)
