@@ -306,7 +306,7 @@ def main():
                          "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": 2.0 * nq * (hi - lo) * d / (sc2a * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                          "kernel": "scan_bf16_w16_kernel<1, true> (16x16x32 MFMA)"}}
-        # the reference's default depth (--depth 1000, src/pretrain_finetune1.sh:218-228): one query part, 3k candidates
+        # the reference's default depth (--depth 1000, src/pretrain_finetune1.sh:218-228): one query part, 2k candidates
         k_deep = 1000
         old_k = k
         k = k_deep
@@ -317,7 +317,7 @@ def main():
         ix.set_param("f32_scan", 0)
         k = old_k
         extra["depth_1000"] = {
-            "what": "top-1000 on the same index (the reference's default --depth): bf16 scan keeping 3000 candidates per query + exact fp32 rescoring vs the fp32 scan",
+            "what": "top-1000 on the same index (the reference's default --depth): bf16 scan keeping `candidates` per query + exact fp32 rescoring vs the fp32 scan",
             "bit_identical": bool(torch.equal(I4, I5)) and bool(torch.equal(D4.view(torch.int32), D5.view(torch.int32))),
             "bf16scan_queries_per_s": nq / (el4 / 2), "bf16scan_ms": el4 * 1e3 / 2, "bf16_scan_kernel_ms": sum(sc4) / len(sc4),
             "candidates": bf4["candidates"], "repeated_queries": bf4["fallback_queries"], "rescore_ms": round(bf4["rescore_ms"], 3),

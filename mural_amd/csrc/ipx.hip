@@ -160,6 +160,7 @@ struct ipx_index {
     int bf16_occ = 1;              // ... workgroups per CU with the 2-deep ring (1, 2)
     int bf16_variant = 0;          // 16-wave bf16 scan, one query part: issue order behind the barrier (0..3) + 4 * non-temporal corpus pieces
     int bf16_waves = 0;            // large-batch bf16 scan: 8 (scan_bf16_kernel<4>) or 16 waves (scan_bf16_w16_kernel); 0 = automatic
+    int margin_post = 1;           // bf16 scan: the after-the-fact margin test (rescore_kernel) and the shorter lists it allows
     bool no_small_batch = false;   // diagnostic: always use the 256-query bf16 scan variant
     bool force_f32_scan = false;   // storage 1: use the fp32 scan although a bf16 copy exists
     size_t tile_bytes() const { return (size_t)nks * ipx::STAGE_A_BYTES; }
@@ -790,6 +791,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     rp.id_base = ix->id_base;
     rp.acc_coef = margin_acc_coef(ix->nks_h * ipx::HBK, qparts);
     rp.qparts = qparts;
+    rp.post = ix->margin_post;
     rp.d = d;
     rp.k = k;
     rp.kc = kc;
@@ -898,6 +900,7 @@ int exact_rows_path(ipx_index* ix, const float* qf, const std::vector<int>& sel,
     rp.id_base = ix->id_base;
     rp.acc_coef = 1.f;
     rp.qparts = 1;
+    rp.post = 0;
     rp.d = ix->d;
     rp.k = k;
     rp.kc = kc;
@@ -953,6 +956,7 @@ int merge_outlier_rows(ipx_index* ix, const float* qf, int64_t nq, int k, float*
     rp.id_base = ix->id_base;
     rp.acc_coef = 1.f;
     rp.qparts = 1;
+    rp.post = 0;
     rp.d = ix->d;
     rp.k = k;
     rp.kc = ipx::OUTLIER_MAX;
@@ -1010,6 +1014,23 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
              // list of 300 left 2 of 32 queries to the repeat pass, 450 none; from k = 250 on 2k leaves none);
              // 256 (the number of splits: every split publishes just its best score) while that is >= 2.5k
                            : std::max(256, 5 * k <= 2 * 256 ? 256 : (k <= 256 ? 3 * k : 2 * k));
+    if (ix->margin_post) {
+        // With the after-the-fact margin test (rescore_kernel: the list has to reach e, not 2e, below the k-th score)
+        // the lists shrink to about the square root of their old multiple of k. Measured on the 8.8M x 768 Gaussian
+        // workload (scripts/margin_probe.py; repeated queries of 6980, or of 20 batches of 64):
+        //   fp32 rows + bf16 copy, one part : k = 100 with 256 none (scan 78.9 vs 81.3 ms with 500); k = 1000 with 1800
+        //                                     none (scan 95 ms, rescoring 12.7; with 3000: 120 + 17.2)
+        //   same, hi + lo, 64 queries       : k = 100 with 150: 36 of 1280, 160: 1, 180 and up: none (scan 2.33 ms
+        //                                     against 2.53 with 256); k = 10 with 128: none
+        //   bf16 rows only, one part        : k = 1000 with 1500 none (94 ms); 64 queries, k = 100 with 150: 1, 200: none
+        //   bf16 rows only, hi + lo         : 64 queries, k = 100 with 110: 118 of 1280, 120 and up: none
+        // So: one part for every large batch (2k on fp32 rows, 1.75k on bf16 rows), hi + lo for small ones (2k / 1.5k).
+        qparts = ix->query_parts > 0 ? ix->query_parts : (small ? 2 : 1);
+        kc = ix->force_kc > 0 ? ix->force_kc
+             : qparts == 1 ? std::max(256, ix->storage == 2 ? k + 3 * k / 4 : 2 * k)
+             : ix->storage == 2 ? (small ? std::max(128, k + k / 2) : std::max(256, k + k / 4))
+                           : (small ? std::max(128, 2 * k) : std::max(256, k <= 256 ? 3 * k : 2 * k));
+    }
     kc = std::min(std::max(kc, k), MAX_KC);
 
     const float* qf = dq;
@@ -1036,6 +1057,9 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
         if (rc) return rc;
         for (int& i : still) i = flagged[(size_t)i];
         flagged.swap(still);
+        // most of the batch failed with the longest list too: this depth goes to the fp32 scan until rows are added
+        if (ix->storage == 1 && nq >= 64 && (int64_t)flagged.size() * 2 > nq && ix->force_kc == 0)
+            ix->bf16_fail_k = std::min(ix->bf16_fail_k, k);
     }
     if (ix->storage == 1 && ix->n_outliers > 0)
         if (int rc = merge_outlier_rows(ix, qf, nq, k, dD, dI, st)) return rc;
@@ -1637,6 +1661,10 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
     }
     if (!strcmp(name, "small_f32_limit")) {
         ix->small_f32_limit = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "margin_post")) {
+        ix->margin_post = value != 0;
         return 0;
     }
     if (!strcmp(name, "no_small_batch")) {

@@ -777,8 +777,15 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
 // exact scores >= a_k - e, so the exact k-th best score is >= a_k - e, so every row of the exact
 // top-k has an approximate score >= a_k - 2e. If the candidate list (the K' best approximate
 // scores) reaches below a_k - 2e — or holds every admissible row of the index — it contains the
-// exact top-k: flag = 0. Otherwise flag = 1 and the host repeats the query with a longer list or
-// on the fp32 scan.
+// exact top-k: flag = 0.
+// Second chance, after the fact (`post`): when that test fails, every candidate is scored exactly and s_k, the k-th
+// best EXACT score among them, is known; it bounds the true k-th best exact score from below. A row outside the list
+// has an approximate score <= a_last (the list's last one), hence an exact score <= a_last + e: if a_last + e < s_k
+// no such row can enter the top-k (strictly below: ties cannot either) and the list's exact top-k is the answer.
+// Since s_k >= a_k - e always, this test passes whenever the first one does, and because the measured |approx - exact|
+// is far below the bound e, in practice it asks the list to reach about e below a_k instead of 2e — lists about
+// sqrt() as many times k long (Gaussian tails: the score falls with the log of the rank).
+// Otherwise flag = 1 and the host repeats the query with a longer list or on the fp32 scan.
 struct RescoreParams {
     const float* candD;      // [nq][kc] approximate scores, descending
     const int64_t* candI;    // [nq][kc] id_base + row, -1 = empty (at the end)
@@ -796,6 +803,7 @@ struct RescoreParams {
     int64_t id_base;
     float acc_coef;          // accumulation-error coefficient (host: margin_acc_coef)
     int qparts;              // bf16 parts of the query the scan used (1: hi, 2: hi + lo)
+    int post;                // 1: try the after-the-fact margin test when the a-priori one fails
     int d, nks, x_is_bf16, k, kc, P;
 };
 
@@ -812,7 +820,7 @@ rescore_kernel(const RescoreParams p) {
     float* qs = (float*)smem;                                  // [dpad]
     uint64_t* keys = (uint64_t*)(smem + (size_t)((dpad * 4 + 15) & ~15));   // [P]
     __shared__ float red[8];
-    __shared__ int s_m;
+    __shared__ int s_m, s_post;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t qi = blockIdx.x;
     const float* q = p.q + (p.qmap ? (int64_t)p.qmap[qi] : qi) * (int64_t)p.d;
@@ -842,7 +850,7 @@ rescore_kernel(const RescoreParams p) {
         int lo = 0, hi = p.kc;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (cI[mid] >= 0) lo = mid + 1; else hi = mid; }
         const int nvalid = lo;
-        int m = nvalid, flag = 0;
+        int m = nvalid, flag = 0, post = 0;
         if (p.shared_list) {
             // the outlier rows: every listed row is scored, nothing was cut off
         } else if (eps == 0.f) {
@@ -857,9 +865,11 @@ rescore_kernel(const RescoreParams p) {
                 m = lo;
             } else {
                 flag = 1;                           // includes eps = NaN / inf
+                post = p.post && eps < INFINITY;    // every candidate is scored; decided behind the sort
             }
         }
         s_m = m;
+        s_post = post;
         p.flags[qi] = flag;
         if (p.err && qi == 0) {                            // the scans are done: same stream
             p.flags[p.nq] = *p.err;
@@ -942,6 +952,10 @@ rescore_kernel(const RescoreParams p) {
             }
             __syncthreads();
         }
+    if (s_post && tid == 0) {
+        const uint64_t key = keys[p.k - 1];                    // k <= kc <= P
+        if (key && cD[p.kc - 1] + eps < f32_unordered((uint32_t)(key >> 32))) p.flags[qi] = 0;
+    }
     for (int i = tid; i < p.k; i += 256) {
         const uint64_t key = i < p.P ? keys[i] : 0;
         p.outD[qi * p.k + i] = key ? f32_unordered((uint32_t)(key >> 32)) : -FLT_MAX;

@@ -184,7 +184,7 @@ def test_bf16scan_aspect_queries_and_float16_rows(R):
     for kw in ({"logits": True},):
         D0, I0 = a.search_aspect(E, logits, 100, **kw)
         D1, I1 = b.search_aspect(E, logits, 100, **kw)
-        assert b.last_bf16_stats()["candidates"] == 500
+        assert b.last_bf16_stats()["candidates"] == 256
         assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
 
 
@@ -225,7 +225,7 @@ def test_config2_scale_bf16scan_equals_fp32_scan(R):
     Q = torch.randn((nq, d), generator=g, device=dev, dtype=torch.float32)
     D1, I1 = ix.search_device(Q, k)
     st = ix.last_bf16_stats()
-    assert st["candidates"] == 500 and st["fallback_queries"] < nq // 50
+    assert st["candidates"] == 256 and st["fallback_queries"] < nq // 50
     ix.set_param("f32_scan", 1)
     D0, I0 = ix.search_device(Q, k)
     ix.check()
@@ -277,6 +277,35 @@ def test_margin_rule_against_coherent_rounding_errors(R):
     ix.set_param("bf16_candidates", 0)
     D, I = ix.search(Q, k)
     assert_bits(D, I, Q, X, k)
+
+
+@pytest.mark.parametrize("n,d,nq,k,storage", [(60000, 768, 300, 100, "bf16scan"), (60000, 768, 40, 100, "bf16scan"),
+                                              (40000, 128, 200, 300, "bf16scan"), (60000, 768, 300, 100, "bf16")])
+def test_after_the_fact_margin_test_accepts_shorter_lists_with_the_same_bits(R, n, d, nq, k, storage):
+    """rescore_kernel's second test (list reaches e below the exact k-th score of the candidates) passes whenever the
+    a-priori one (2e below the k-th approximate score) does, so with the same list it never repeats more queries;
+    the shorter default lists it allows return the same bits as the old ones and as the oracle."""
+    X, Q = gaussian(77, (n, d)), gaussian(78, (nq, d))
+    ix = index(R, X, storage)
+    res = {}
+    for post in (0, 1):
+        ix.set_param("margin_post", post)
+        D, I = ix.search(Q, k)
+        res[post] = (D, I, ix.last_bf16_stats())
+        if storage == "bf16scan":
+            assert_bits(D, I, Q, X, k)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+    assert 0 < res[1][2]["candidates"] <= res[0][2]["candidates"]
+    # one forced list length, both rules: the second chance can only take queries off the repeat pass
+    kc = max(128, k + k // 4)
+    ix.set_param("bf16_candidates", kc)
+    rep = {}
+    for post in (0, 1):
+        ix.set_param("margin_post", post)
+        D, I = ix.search(Q, k)
+        rep[post] = ix.last_bf16_stats()["fallback_queries"]
+        assert np.array_equal(I, res[0][1]) and np.array_equal(D.view(np.uint32), res[0][0].view(np.uint32))
+    assert rep[1] <= rep[0]
 
 
 def _with_outliers(X, rows, rng, special=True):
@@ -346,7 +375,8 @@ def test_index_remembers_a_depth_the_bf16_scan_cannot_serve(R):
     n, d, nq, k = 20000, 96, 128, 700
     rng = np.random.default_rng(3)
     X = gaussian(8, (n, d))
-    X[rng.choice(np.arange(3000, n), size=400, replace=False)] *= np.float32(30.0)
+    # (300 x the ordinary norm: the repeat pass with the longest list, a fifth of the rows, fails as well)
+    X[rng.choice(np.arange(3000, n), size=400, replace=False)] *= np.float32(300.0)
     Q = gaussian(9, (nq, d))
     ix = index(R, X, "bf16scan")
     rD, rI = O.topk_total_order(O.scores_mfma_order(Q, X), k)
