@@ -183,6 +183,11 @@ int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k
  *                  search scores them exactly on the side and merges them in, so they do not widen the other rows'
  *                  margin. Same results, bit for bit.
  *   "bf16_candidates" : candidates per query the bf16 scan keeps (0 = automatic).
+ *   "margin_post": 1 (default) = a candidate list that fails the a-priori sufficiency test (it reaches 2e below
+ *                  the k-th approximate score) is still accepted when, after exact rescoring, its last approximate
+ *                  score + e lies below the k-th best exact score of its candidates — equally provable, about half
+ *                  the margin in practice, so the automatic lists are shorter (2k / 1.75k candidates); 0 = the
+ *                  a-priori test alone with its longer lists. Results do not depend on it.
  *   "query_parts": bf16 parts per query in the bf16 scan: 1 = bf16(q); 2 = hi + lo (16 bits of
  *                  the query, twice the MFMA work, a far smaller margin); 0 = automatic.
  *   "f32_scan"   : 1 = storage 1 searches with the fp32 scan (A/B measurements on one index).
