@@ -281,17 +281,14 @@ scan_f32_small_kernel(const ScanParams p, const int nsortwaves) {
             const uint32_t* col = p.pub + (size_t)qb * nvals * BQ_ + q;
             // (K-th largest of the published values instead of their minimum when they fit 32 per thread: with
             // k = 100 and 512 splits the minimum admits ~3.5k rows per query over the index, the 100-th largest ~110)
-            // More values than 32 per thread (64-query tile: 8 threads per query): the k-th largest of the FIRST
-            // 32 x TPQ of them — any subset of the bests of disjoint row sets gives a valid floor (256 of 512: ~250 rows).
-            const int nv = nvals < 32 * TPQ ? nvals : 32 * TPQ;
-            const bool kth = p.kth && (nv == nvals || p.k <= nv);
+            const bool kth = nvals <= 32 * TPQ && p.kth;
             for (int attempt = 0; attempt < (rounds == 1 ? 64 : 1); ++attempt) {
                 if (tid < BQ_) tmin[tid] = 0xffffffffu;
                 __syncthreads();
                 if (kth) {
-                    const int K = p.k < nv ? p.k : nv;
+                    const int K = p.k < nvals ? p.k : nvals;
                     const uint32_t pre = kth_largest_published<32, TPQ>(p.pub + (size_t)qb * nvals * BQ_ + tid / TPQ, BQ_,
-                                                                        nv, K, tid % TPQ);
+                                                                        nvals, K, tid % TPQ);
                     if (tid % TPQ == 0) tmin[tid / TPQ] = pre;
                 } else {
                     uint32_t v = 0xffffffffu;
