@@ -194,8 +194,6 @@ int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k
  *   "max_splits" : upper bound on the corpus splits per query block (0 = automatic).
  *   "small_f32_limit" : fp32 scans of up to this many queries use the 32/64-query tile that
  *                  streams the corpus at the HBM rate (default 192; results do not depend on it).
- *   "f32_small_kth" : fp32 small-batch scan, up to 32 queries: the union bound is the k-th largest of the splits'
- *                  published bests (1, default) or their minimum (0). Results do not depend on it.
  *   "no_small_batch" : 1 = always use the 256-query tiles (A/B measurements, tests).
  *   "bf16_waves" : large-batch bf16 scan with 8 or 16 waves per workgroup (0 = automatic: 16; results do not
  *                  depend on it).

@@ -161,7 +161,6 @@ struct ipx_index {
     int bf16_variant = 0;          // 16-wave bf16 scan, one query part: issue order behind the barrier (0..3) + 4 * non-temporal corpus pieces
     int bf16_waves = 0;            // large-batch bf16 scan: 8 (scan_bf16_kernel<4>) or 16 waves (scan_bf16_w16_kernel); 0 = automatic
     int margin_post = 1;           // bf16 scan: the after-the-fact margin test (rescore_kernel) and the shorter lists it allows
-    int f32_small_kth = 1;         // fp32 small-batch scan: K-th largest union bound (0 = the minimum of the bests)
     bool no_small_batch = false;   // diagnostic: always use the 256-query bf16 scan variant
     bool force_f32_scan = false;   // storage 1: use the fp32 scan although a bf16 copy exists
     size_t tile_bytes() const { return (size_t)nks * ipx::STAGE_A_BYTES; }
@@ -364,7 +363,6 @@ int scan_f32_small_launch(ipx_index* ix, const SmallGeom& g, const SmallBufs& b,
     p.pub = (uint32_t*)((char*)b.pub + g.ctr_bytes);
     p.run_tiles = g.R;
     p.r = (k + S - 1) / S;
-    p.kth = ix->f32_small_kth;
     p.trace = nullptr;
     if (ix->trace_on && ix->trace.bytes >= (size_t)g.G * 20 * sizeof(uint64_t)) p.trace = (uint64_t*)ix->trace.p;
     p.N = ix->ntotal;
@@ -1667,10 +1665,6 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
     }
     if (!strcmp(name, "margin_post")) {
         ix->margin_post = value != 0;
-        return 0;
-    }
-    if (!strcmp(name, "f32_small_kth")) {
-        ix->f32_small_kth = value != 0;
         return 0;
     }
     if (!strcmp(name, "no_small_batch")) {

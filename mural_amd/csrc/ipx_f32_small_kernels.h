@@ -279,26 +279,16 @@ scan_f32_small_kernel(const ScanParams p, const int nsortwaves) {
             const int per = (nvals + TPQ - 1) / TPQ;
             const int s_lo = part * per, s_hi = s_lo + per < nvals ? s_lo + per : nvals;
             const uint32_t* col = p.pub + (size_t)qb * nvals * BQ_ + q;
-            // (K-th largest of the published values instead of their minimum when they fit 32 per thread: with
-            // k = 100 and 512 splits the minimum admits ~3.5k rows per query over the index, the 100-th largest ~110)
-            const bool kth = nvals <= 32 * TPQ && p.kth;
             for (int attempt = 0; attempt < (rounds == 1 ? 64 : 1); ++attempt) {
                 if (tid < BQ_) tmin[tid] = 0xffffffffu;
                 __syncthreads();
-                if (kth) {
-                    const int K = p.k < nvals ? p.k : nvals;
-                    const uint32_t pre = kth_largest_published<32, TPQ>(p.pub + (size_t)qb * nvals * BQ_ + tid / TPQ, BQ_,
-                                                                        nvals, K, tid % TPQ);
-                    if (tid % TPQ == 0) tmin[tid / TPQ] = pre;
-                } else {
-                    uint32_t v = 0xffffffffu;
+                uint32_t v = 0xffffffffu;
 #pragma unroll 8
-                    for (int s2 = s_lo; s2 < s_hi; ++s2) {
-                        const uint32_t x = __hip_atomic_load(col + (size_t)s2 * BQ_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v = x < v ? x : v;
-                    }
-                    atomicMin(&tmin[q], v);
+                for (int s2 = s_lo; s2 < s_hi; ++s2) {
+                    const uint32_t x = __hip_atomic_load(col + (size_t)s2 * BQ_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = x < v ? x : v;
                 }
+                atomicMin(&tmin[q], v);
                 __syncthreads();
                 // queries beyond nq never publish: they do not count as "missing"
                 const bool missing = tid < BQ_ && (int64_t)qb * BQ_ + tid < p.nq && tmin[tid] == 0;

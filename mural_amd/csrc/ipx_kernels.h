@@ -224,7 +224,6 @@ struct ScanParams {
     const float* ceilD = nullptr;
     const int64_t* ceilI = nullptr;
     int map = 0;         // bf16 large-batch scans: query blocks per group of decode_block (0 = query-block-major)
-    int kth = 0;         // scan_f32_small_kernel: union bound = K-th largest of the published bests (else their minimum)
     int nselect = 0;     // scan_bf16_w16_kernel: waves that run the episodes' selections (4 bytes of LDS per queue slot
                          // each; the final sort takes 8: `nsortwaves`); 0 = nsortwaves
 };
