@@ -98,8 +98,14 @@ for c in range(cases):
                                          "bf16_map": int(rng.choice([0, 1]))}),
                      ("bf16 direct corpus", {"no_small_batch": 1, "query_parts": 1, "bf16_pp": int(rng.choice([3, 4])),
                                              "bf16_map": int(rng.choice([0, 2, 5]))})]
+    if os.environ.get("ONLY_CASE") and c != int(os.environ["ONLY_CASE"]):      # replay one case of a seed
+        del ix
+        continue
     for name, params in variants:
-        for key in ("f32_scan", "no_small_batch", "query_parts", "bf16_waves", "bf16_variant", "bf16_map", "bf16_pp", "bf16_ring"):
+        if os.environ.get("FORCE_KC") and name.startswith("bf16") and storage == "bf16scan":
+            # diagnostic: a forced candidate count also lifts storage 1's depth limit of the bf16 scan
+            params = dict(params, bf16_candidates=int(os.environ["FORCE_KC"]))
+        for key in ("bf16_candidates", "f32_scan", "no_small_batch", "query_parts", "bf16_waves", "bf16_variant", "bf16_map", "bf16_pp", "bf16_ring"):
             ix.set_param(key, 0)
         ix.set_param("bf16_occ", 1)
         ix.set_param("bf16_shape16", 1)
@@ -116,6 +122,13 @@ for c in range(cases):
             bad = np.argwhere(I != rI)
             print("MISMATCH case", c, dict(n=n, d=d, nq=nq, k=k, kind=kind, storage=storage, ms=ms, adds=adds, variant=name),
                   "first", bad[:3].tolist(), flush=True)
+            if os.environ.get("ONLY_CASE"):
+                rows = sorted(set(bad[:, 0].tolist()))
+                print("  params", params, "bf16", ix.last_bf16_stats(), "geometry", ix.last_geometry(), flush=True)
+                print("  queries", rows[:10], "of", nq, "| first bad rank per query", [int(np.argmax(I[r] != rI[r])) for r in rows[:10]], flush=True)
+                r0 = rows[0]; j = int(np.argmax(I[r0] != rI[r0]))
+                print("  got", I[r0, j:j + 6].tolist(), D[r0, j:j + 3].tolist(), "want", rI[r0, j:j + 6].tolist(), rD[r0, j:j + 3].tolist(), flush=True)
+                continue
             sys.exit(1)
     del ix
     if c % 10 == 9:
