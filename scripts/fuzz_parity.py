@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from oracle import oracle as O
+from mural_amd import _lib
+if os.environ.get("IPX_LIB"):      # a diagnostic build next to libipx.so
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["IPX_LIB"])
 from mural_amd.faiss_retriever.retriever import FlatIPIndex
 
 def bf16_round(x):
@@ -122,7 +125,7 @@ for c in range(cases):
             bad = np.argwhere(I != rI)
             print("MISMATCH case", c, dict(n=n, d=d, nq=nq, k=k, kind=kind, storage=storage, ms=ms, adds=adds, variant=name),
                   "first", bad[:3].tolist(), flush=True)
-            if os.environ.get("ONLY_CASE"):
+            if os.environ.get("ONLY_CASE") or os.environ.get("DETAILS"):
                 rows = sorted(set(bad[:, 0].tolist()))
                 print("  params", params, "bf16", ix.last_bf16_stats(), "geometry", ix.last_geometry(), flush=True)
                 print("  queries", rows[:10], "of", nq, "| first bad rank per query", [int(np.argmax(I[r] != rI[r])) for r in rows[:10]], flush=True)
