@@ -231,6 +231,11 @@ int ipx_last_bf16_stats(ipx_index* idx, float* rescore_ms, int* candidates, int6
  * search. No counterpart in the reference; bookkeeping for tests. */
 int ipx_outlier_rows(const ipx_index* idx);
 
+/* Queries of the most recent bf16 search that no candidate list could serve (the repeat pass with the longest list
+ * failed too, or the norm bound is not finite) and that were answered by the fp32 scan (storage 1) or the exact pass
+ * over every stored row (storage 2). No counterpart in the reference; bookkeeping for tests and the bench. */
+int64_t ipx_last_exact_queries(const ipx_index* idx);
+
 /* Launch geometry chosen by the most recent search: workgroups, corpus splits per
  * query block, candidate-queue capacity. For bench / DESIGN.md bookkeeping. */
 int ipx_last_geometry(const ipx_index* idx, int* workgroups, int* splits, int* queue_cap);

@@ -14,7 +14,7 @@ SYMBOLS = [
     "ipx_last_error", "ipx_version", "ipx_device_count", "ipx_create", "ipx_destroy", "ipx_dim",
     "ipx_ntotal", "ipx_reserve", "ipx_set_id_base", "ipx_add", "ipx_search", "ipx_search_noalloc", "ipx_search_aspect", "ipx_search_pooled", "ipx_pool", "ipx_add_pooled",
     "ipx_merge_topk", "ipx_merge_topk_packed", "ipx_packed_block_bytes", "ipx_set_param", "ipx_read_trace", "ipx_check", "ipx_set_timing", "ipx_last_timing", "ipx_last_geometry",
-    "ipx_last_bf16_stats", "ipx_outlier_rows",
+    "ipx_last_bf16_stats", "ipx_outlier_rows", "ipx_last_exact_queries",
     "ipx_write_ranking", "ipx_write_ranking_lookup", "ipx_format_score",
 ]
 
@@ -78,6 +78,8 @@ def lib():
     L.ipx_last_geometry.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.ipx_last_bf16_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32), C.POINTER(i64)]
     L.ipx_outlier_rows.argtypes = [vp]
+    L.ipx_last_exact_queries.argtypes = [vp]
+    L.ipx_last_exact_queries.restype = i64
     L.ipx_write_ranking.argtypes = [C.c_char_p, vp, i32, vp, i32, vp, vp, i64, i32]
     L.ipx_write_ranking_lookup.argtypes = [C.c_char_p, vp, i32, vp, vp, i32, i64, vp, vp, i64, i32]
     L.ipx_format_score.argtypes = [C.c_float, C.c_char_p, C.c_size_t]

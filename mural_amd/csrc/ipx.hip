@@ -146,7 +146,8 @@ struct ipx_index {
     bool ev_valid = false, ev_merge = false, ev_rescore = false;
     int last_wgs = 0, last_S = 0, last_cap = 0;
     int last_kc = 0;                 // candidates per query of the last bf16 scan (0 = fp32 scan)
-    int64_t last_fallback = 0;       // queries the last search repeated on the fp32 scan
+    int64_t last_fallback = 0;       // queries whose first bf16 pass failed the sufficiency check
+    int64_t last_exact = 0;          // ... of which the repeat pass failed too: answered by the fp32 scan / the exact pass
     int max_splits = 0;      // 0 = automatic
     int force_kc = 0;        // 0 = automatic candidate count
     int query_parts = 0;     // 0 = automatic; 1 / 2 bf16 parts per query in the bf16 scan
@@ -344,7 +345,8 @@ SmallGeom small_geometry(const ipx_index* ix, int64_t nq, int k, int split_cap) 
 
 // Launches only: no allocation, no synchronisation. `record`: HIP events around the kernels (ipx_set_timing).
 int scan_f32_small_launch(ipx_index* ix, const SmallGeom& g, const SmallBufs& b, const float* dq, const float* dw, int A,
-                          int logits, int64_t nq, int k, float* dD, int64_t* dI, hipStream_t st, bool record, bool primary) {
+                          int logits, int64_t nq, int k, float* dD, int64_t* dI, hipStream_t st, bool record, bool primary,
+                          bool set_attr = true) {
     const int S = g.S;
     IPX_HIP(hipMemsetAsync(b.pub, 0, g.pub_bytes, st));
     if (record) IPX_HIP(hipEventRecord(ix->ev[0], st));
@@ -379,7 +381,7 @@ int scan_f32_small_launch(ipx_index* ix, const SmallGeom& g, const SmallBufs& b,
     const int lds = std::max(g.ring, g.nsortwaves * g.cap * 8) + ipx::LDS_STATE_BYTES;
     {
         void (*kern)(const ipx::ScanParams, const int) = g.qt == 1 ? ipx::scan_f32_small_kernel<1> : ipx::scan_f32_small_kernel<2>;
-        IPX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if (set_attr) IPX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(kern, dim3(g.G), dim3(512), lds, st, p, g.nsortwaves);
     }
     IPX_HIP(hipGetLastError());
@@ -593,7 +595,7 @@ int scan_f32_deep(ipx_index* ix, const float* dq, const float* dw, int A, int lo
         const int64_t n = nq * (int64_t)kk;
         hipLaunchKernelGGL(ipx::deep_collect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                            (const float*)ix->deepD.p, (const int64_t*)ix->deepI.p, nq, kk, dD, dI, k, (int)off,
-                           (float*)ix->ceilD.p, (int64_t*)ix->ceilI.p);
+                           (float*)ix->ceilD.p, (int64_t*)ix->ceilI.p, (int*)nullptr);
         IPX_HIP(hipGetLastError());
     }
     return 0;
@@ -609,9 +611,10 @@ float margin_acc_coef(int d_pad, int qparts) {
 
 // One bf16 pass over nq row-major fp32 queries (device): pack -> bf16 scan keeping kc candidates
 // -> merge -> exact rescoring into dD / dI. Synchronises the stream and returns in `flagged` the
-// queries whose candidate list could not be proven sufficient (their rows of dD / dI are not final).
+// queries whose candidate list could not be proven sufficient (their rows of dD / dI are not final), and in `hard`
+// those of them that no bf16 list of any length can serve (rescore_kernel's flag 2: a non-finite norm bound).
 int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qparts, float* dD, int64_t* dI,
-              hipStream_t st, bool primary, std::vector<int>& flagged) {
+              hipStream_t st, bool primary, std::vector<int>& flagged, std::vector<int>& hard) {
     const int d = ix->d, nks = ix->nks_h;
     const int64_t N = ix->ntotal;
     const size_t ncand = (size_t)nq * kc;
@@ -833,8 +836,9 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
         return fail(IPX_ERR_STATE, "search: candidate queue overflow (internal invariant violated)");
     }
     flagged.clear();
+    hard.clear();
     for (int64_t i = 0; i < nq; ++i)
-        if (flags[(size_t)i]) flagged.push_back((int)i);
+        if (flags[(size_t)i]) (flags[(size_t)i] == 2 ? hard : flagged).push_back((int)i);
     return 0;
 }
 
@@ -1042,25 +1046,32 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
         IPX_HIP(hipGetLastError());
         qf = (const float*)ix->qfused.p;
     }
-    std::vector<int> flagged;
-    if (int rc = bf16_pass(ix, qf, nq, k, kc, qparts, dD, dI, st, true, flagged)) return rc;
-    ix->last_fallback = (int64_t)flagged.size();
-    // most of a batch failed with a list that is already half the longest one: the repeat pass would fail too
-    const bool hopeless = ix->storage == 1 && nq >= 64 && (int64_t)flagged.size() * 2 > nq && 2 * kc > MAX_KC &&
+    // flagged: a longer list may do; hard: no bf16 list can (they skip the repeat pass)
+    std::vector<int> flagged, hard;
+    if (int rc = bf16_pass(ix, qf, nq, k, kc, qparts, dD, dI, st, true, flagged, hard)) return rc;
+    const int64_t nfail = (int64_t)(flagged.size() + hard.size());
+    ix->last_fallback = nfail;
+    // most of a batch failed with a list that is already half the longest one (or for good): the repeat pass would
+    // fail too
+    const bool hopeless = ix->storage == 1 && nq >= 64 && nfail * 2 > nq && (2 * kc > MAX_KC || hard.size() * 2 > (size_t)nq) &&
                           ix->force_kc == 0;
     if (hopeless) ix->bf16_fail_k = std::min(ix->bf16_fail_k, k);
     if (!flagged.empty() && !hopeless && (kc < MAX_KC || qparts == 1)) {    // longest list, hi + lo query
-        std::vector<int> still;
+        std::vector<int> still, still_hard;
         int rc = redo_queries(ix, qf, flagged, k, dD, dI, st, [&](const float* q2, int64_t n2, float* D2, int64_t* I2) {
-            return bf16_pass(ix, q2, n2, k, MAX_KC, 2, D2, I2, st, false, still);
+            return bf16_pass(ix, q2, n2, k, MAX_KC, 2, D2, I2, st, false, still, still_hard);
         });
         if (rc) return rc;
+        still.insert(still.end(), still_hard.begin(), still_hard.end());
         for (int& i : still) i = flagged[(size_t)i];
         flagged.swap(still);
         // most of the batch failed with the longest list too: this depth goes to the fp32 scan until rows are added
-        if (ix->storage == 1 && nq >= 64 && (int64_t)flagged.size() * 2 > nq && ix->force_kc == 0)
+        if (ix->storage == 1 && nq >= 64 && (int64_t)(flagged.size() + hard.size()) * 2 > nq && ix->force_kc == 0)
             ix->bf16_fail_k = std::min(ix->bf16_fail_k, k);
     }
+    flagged.insert(flagged.end(), hard.begin(), hard.end());
+    std::sort(flagged.begin(), flagged.end());
+    ix->last_exact = (int64_t)flagged.size();
     if (ix->storage == 1 && ix->n_outliers > 0)
         if (int rc = merge_outlier_rows(ix, qf, nq, k, dD, dI, st)) return rc;
     if (flagged.empty()) return 0;
@@ -1114,6 +1125,7 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
     ix->ev_rescore = false;
     ix->last_kc = 0;
     ix->last_fallback = 0;
+    ix->last_exact = 0;
 
     if (N == 0) {
         // empty index: every slot is (-FLT_MAX, -1), as faiss returns for ntotal == 0
@@ -1121,20 +1133,17 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
                            (int64_t)nout);
         IPX_HIP(hipGetLastError());
     } else {
-        // the error word is cleared when it is allocated and whenever it was found set: no fill per search
-        const bool fresh = ix->err.p == nullptr;
-        if (int rc = ix->err.ensure(256)) return rc;
-        if (fresh) IPX_HIP(hipMemsetAsync(ix->err.p, 0, 256, st));
+        // the error word exists since ipx_create and is cleared whenever it was found set: no fill per search
         ix->last_err = (int*)ix->err.p;
-        // bf16 scan whenever the index keeps a bf16 copy and the candidate list (2k with hi + lo
-        // query parts, 1.25k on bf16 rows) fits IPX_MAX_K; deeper searches take the fp32 scan,
-        // which bf16-only storage does not have
-        if (ix->storage == 2 && k > IPX_MAX_K * 4 / 5 && ix->force_kc == 0)
+        // bf16 scan whenever the index keeps a bf16 copy and the depth is one its candidate lists can serve (2k
+        // candidates on fp32 rows, 1.25k on bf16 rows, at most MAX_KC); deeper searches take the fp32 scan, which
+        // bf16-only storage does not have. A forced candidate count ("bf16_candidates") changes the list length,
+        // never these limits.
+        if (ix->storage == 2 && k > IPX_MAX_K * 4 / 5)
             return fail(IPX_ERR_ARG, "search: bf16 storage serves k <= " + std::to_string(IPX_MAX_K * 4 / 5) +
                         " (the candidate list is 1.25 k); use storage 0 or 1 for deeper searches");
         const bool bf16 = ix->storage == 2 ||
-                          (ix->storage == 1 && !ix->force_f32_scan && (2 * k <= IPX_MAX_K || ix->force_kc > 0) &&
-                           (k < ix->bf16_fail_k || ix->force_kc > 0));
+                          (ix->storage == 1 && !ix->force_f32_scan && k <= IPX_MAX_K && k < ix->bf16_fail_k);
         int rc = bf16 ? scan_bf16_path(ix, dq, dw, A, logits, nq, k, dD, dI, st)
                  : k > IPX_MAX_K ? scan_f32_deep(ix, dq, dw, A, logits, nq, k, dD, dI, st)
                                  : scan_f32_path(ix, dq, dw, A, logits, nq, k, dD, dI, st, true);
@@ -1147,7 +1156,10 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
         int errflag = 0;
         if (N > 0) IPX_HIP(hipMemcpyAsync(&errflag, ix->err.p, sizeof(int), hipMemcpyDeviceToHost, st));
         IPX_HIP(hipStreamSynchronize(st));
-        if (errflag) return fail(IPX_ERR_STATE, "search: candidate queue overflow (internal invariant violated)");
+        if (errflag) {
+            (void)hipMemsetAsync(ix->err.p, 0, 256, st);      // found set: cleared for the next search
+            return fail(IPX_ERR_STATE, "search: candidate queue overflow (internal invariant violated)");
+        }
     }
     return 0;
 }
@@ -1156,7 +1168,8 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
 // lists are cut into chunks of at most IPX_MAX_K entries and merged by merge_topk_kernel, IPX_MAX_K output ranks per
 // pass; pass j blanks every entry not strictly after the last entry of pass j-1 (deep_stage_kernel), as the scans of a
 // deep search do. Queries go through in batches so the staged copy stays small. Synchronises the stream before it
-// frees its buffers. (An entry present twice with the same score and id is returned once if a pass ends on it.)
+// frees its buffers. An entry present several times with the same score and id (one document in two shards' lists) is
+// returned as often as it is present, as ResultHeap does, also when a pass ends between its copies (cN / eq below).
 int merge_deep(const float* dD, const int64_t* dI, int S, int64_t nq, int k_in, int k_out, float* oD, int64_t* oI, hipStream_t st) {
     const int chunk = std::min(k_in, (int)IPX_MAX_K), nchunks = (k_in + chunk - 1) / chunk, step = IPX_MAX_K;
     const int64_t k_live = std::min<int64_t>(k_out, (int64_t)S * k_in);
@@ -1168,12 +1181,13 @@ int merge_deep(const float* dD, const int64_t* dI, int S, int64_t nq, int k_in, 
     if (k_live == 0) return 0;
     const int64_t nb_max = std::min<int64_t>(nq, 512);
     const int64_t Sx = (int64_t)S * nchunks;
-    DevBuf sD, sI, tD, tI, cD, cI;
-    auto cleanup = [&]() { for (DevBuf* b : {&sD, &sI, &tD, &tI, &cD, &cI}) b->release(); };
+    DevBuf sD, sI, tD, tI, cD, cI, cN, eq;
+    auto cleanup = [&]() { for (DevBuf* b : {&sD, &sI, &tD, &tI, &cD, &cI, &cN, &eq}) b->release(); };
     int rc = 0;
     if ((rc = sD.ensure((size_t)Sx * nb_max * chunk * sizeof(float))) || (rc = sI.ensure((size_t)Sx * nb_max * chunk * sizeof(int64_t))) ||
         (rc = tD.ensure((size_t)nb_max * step * sizeof(float))) || (rc = tI.ensure((size_t)nb_max * step * sizeof(int64_t))) ||
-        (rc = cD.ensure((size_t)nq * sizeof(float))) || (rc = cI.ensure((size_t)nq * sizeof(int64_t)))) {
+        (rc = cD.ensure((size_t)nq * sizeof(float))) || (rc = cI.ensure((size_t)nq * sizeof(int64_t))) ||
+        (rc = cN.ensure((size_t)nq * sizeof(int))) || (rc = eq.ensure((size_t)nq * sizeof(int)))) {
         cleanup();
         return rc;
     }
@@ -1183,9 +1197,11 @@ int merge_deep(const float* dD, const int64_t* dI, int S, int64_t nq, int k_in, 
         for (int64_t off = 0; off < k_live && e == hipSuccess; off += step) {
             const int kk = (int)std::min<int64_t>(step, k_live - off);
             const int64_t nst = Sx * nb * chunk;
+            if (off) e = hipMemsetAsync((int*)eq.p + q0, 0, (size_t)nb * sizeof(int), st);
+            if (e != hipSuccess) break;
             hipLaunchKernelGGL(ipx::deep_stage_kernel, dim3((unsigned)((nst + 255) / 256)), dim3(256), 0, st, dD, dI, S, nq, k_in,
                                chunk, nchunks, q0, nb, off ? (const float*)cD.p : nullptr, off ? (const int64_t*)cI.p : nullptr,
-                               (float*)sD.p, (int64_t*)sI.p);
+                               (const int*)cN.p, (int*)eq.p, (float*)sD.p, (int64_t*)sI.p);
             const int P = next_pow2(std::max(chunk, kk));
             const int mlds = P * 24;
             if (mlds > 64 * 1024)
@@ -1197,7 +1213,7 @@ int merge_deep(const float* dD, const int64_t* dI, int S, int64_t nq, int k_in, 
             const int64_t n = nb * (int64_t)kk;
             hipLaunchKernelGGL(ipx::deep_collect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)tD.p,
                                (const int64_t*)tI.p, nb, kk, oD + q0 * k_out, oI + q0 * k_out, k_out, (int)off,
-                               (float*)cD.p + q0, (int64_t*)cI.p + q0);
+                               (float*)cD.p + q0, (int64_t*)cI.p + q0, (int*)cN.p + q0);
             e = hipGetLastError();
         }
     }
@@ -1251,11 +1267,23 @@ int ipx_create(int d, int device, ipx_index** out) {
         int rc = guard.err != hipSuccess
                      ? fail(IPX_ERR_HIP, std::string("create: hipSetDevice: ") + hipGetErrorString(guard.err))
                      : scratch_ptr(device, &ws);
+        // the error word of this index's searches, and the launch attributes ipx_search_noalloc's kernels need: that
+        // entry point itself then neither allocates nor touches the module
+        if (!rc) rc = ix->err.ensure(256);
+        if (!rc && hipMemset(ix->err.p, 0, 256) != hipSuccess) rc = fail(IPX_ERR_HIP, "create: hipMemset");
+        if (!rc) {
+            const int l1 = ipx::SCfg<1>::RING + ipx::LDS_STATE_BYTES, l2 = ipx::SCfg<2>::RING + ipx::LDS_STATE_BYTES;
+            if (hipFuncSetAttribute((const void*)ipx::scan_f32_small_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, l1) != hipSuccess ||
+                hipFuncSetAttribute((const void*)ipx::scan_f32_small_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2) != hipSuccess)
+                rc = fail(IPX_ERR_HIP, "create: hipFuncSetAttribute");
+        }
         if (rc) {
+            ix->err.release();
             delete ix;
             return rc;
         }
     }
+    ix->last_err = (int*)ix->err.p;
     *out = ix;
     return 0;
 }
@@ -1385,6 +1413,7 @@ int ipx_search_noalloc(ipx_index* ix, const float* q, int64_t nq, int k, float* 
     ix->ev_valid = ix->ev_merge = ix->ev_rescore = false;
     ix->last_kc = 0;
     ix->last_fallback = 0;
+    ix->last_exact = 0;
     if (ix->ntotal == 0) {
         const int64_t nout = nq * k;
         hipLaunchKernelGGL(ipx::fill_empty_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, out_D, out_I, nout);
@@ -1407,19 +1436,18 @@ int ipx_search_noalloc(ipx_index* ix, const float* q, int64_t nq, int k, float* 
     char* at = (char*)ws;
     auto carve = [&](size_t bytes) { char* r = at; at += (bytes + 255) / 256 * 256; return (void*)r; };
     SmallBufs b;
-    b.err = (int*)carve(256);
+    b.err = (int*)ix->err.p;          // per index (allocated by ipx_create): ipx_check(idx) reports this index's searches
     b.Qp = carve(g.qp_bytes);
     b.cand = carve(g.cand_bytes);
     b.partD = carve(g.partD_bytes);
     b.partI = carve(g.partI_bytes);
     b.flags = carve(g.flags_bytes);
     b.pub = carve(g.pub_bytes);
-    // the workspace keeps the previous call's contents: what must start at zero is cleared here (the error word)
-    // and in the launch (run counters and published bounds); queues, lists and flags are written before they are read
-    IPX_HIP(hipMemsetAsync(b.err, 0, 256, st));
+    // the workspace keeps the previous call's contents: what must start at zero is cleared in the launch (run counters
+    // and published bounds); queues, lists and flags are written before they are read
     ix->last_err = b.err;
     const bool record = ix->timing && ix->ev[0] != nullptr;     // events are never created here
-    return scan_f32_small_launch(ix, g, b, q, nullptr, 0, 0, nq, k, out_D, out_I, st, record, true);
+    return scan_f32_small_launch(ix, g, b, q, nullptr, 0, 0, nq, k, out_D, out_I, st, record, true, /*set_attr=*/false);
 }
 
 int ipx_search_aspect(ipx_index* ix, const float* aspect_emb, const float* w, int A, int w_is_logits, int64_t nq,
@@ -1756,6 +1784,8 @@ int ipx_last_bf16_stats(ipx_index* ix, float* rescore_ms, int* candidates, int64
 }
 
 int ipx_outlier_rows(const ipx_index* ix) { return ix ? ix->n_outliers : 0; }
+
+int64_t ipx_last_exact_queries(const ipx_index* ix) { return ix ? ix->last_exact : 0; }
 
 int ipx_last_geometry(const ipx_index* ix, int* workgroups, int* splits, int* queue_cap) {
     if (!ix) return fail(IPX_ERR_ARG, "last_geometry: null index");

@@ -842,6 +842,15 @@ rescore_kernel(const RescoreParams p) {
     const float dqn = sqrtf(red[4] + red[5] + red[6] + red[7]);
     const float Mx = sqrtf(__uint_as_float(p.maxsq[0])), Dx = sqrtf(__uint_as_float(p.maxsq[1]));
     const float eps = 1.002f * ((qn + dqn) * Dx + dqn * Mx) + p.acc_coef * (qn + dqn) * (Mx + Dx);
+    // Every partial sum of either chain is bounded by (|q| + |dq|)(Mx + Dx). Only while that stays well inside the
+    // fp32 range is an approximate score a finite number whenever the exact one is: with an inf (or overflowing)
+    // element among the scanned rows the bf16 chain can end in NaN — inf * hi + inf * lo with parts of opposite
+    // sign, inf * 0 with a query element that rounds to zero — where the exact chain ends in +inf, and a NaN score
+    // is never admitted to a candidate list. Such a row would be missing from the list WITHOUT the list being full,
+    // so "the list holds every admissible row" proves nothing then: the query is flagged 2 (no bf16 list of any
+    // length can be trusted; the host sends it to the exact path directly).
+    const float span = (qn + dqn) * (Mx + Dx);
+    const bool tame = span < 1e38f;                  // false for NaN / inf
 
     const float* cD = p.candD + (p.shared_list ? 0 : qi * (int64_t)p.kc);
     const int64_t* cI = p.candI + (p.shared_list ? 0 : qi * (int64_t)p.kc);
@@ -853,6 +862,8 @@ rescore_kernel(const RescoreParams p) {
         int m = nvalid, flag = 0, post = 0;
         if (p.shared_list) {
             // the outlier rows: every listed row is scored, nothing was cut off
+        } else if (!tame) {
+            flag = 2;
         } else if (eps == 0.f) {
             // a zero query (or an all-zero index): every approximate score IS the exact score, the list is in the
             // result order (score desc, id asc) already — its first k entries are the answer, whatever ties follow
@@ -884,6 +895,7 @@ rescore_kernel(const RescoreParams p) {
     // ones — for RS_KB K-stages in a row; the lines go through LDS to lane r < 16, which owns
     // candidate r and runs the ordered fmaf chain (the order of the fp32 scan's MFMA).
     for (int i = tid; i < p.P; i += 256) keys[i] = 0;
+    __syncthreads();            // a wave writes keys that other waves' threads cleared
     char* stage = (char*)(keys + p.P) + wave * (RS_KB * 16 * RS_ROW);
     const int R = p.x_is_bf16 ? HBD : BD;                 // rows per tile of the packed layout
     const size_t ks_stride = (size_t)R * 64;              // bytes between a row's consecutive K-stages

@@ -846,7 +846,8 @@ __device__ __forceinline__ bool entry_before(uint32_t osa, int64_t ida, uint32_t
 // the next pass's ceiling (id -1: the pass ran out of hits, the next ones return nothing).
 __global__ void __launch_bounds__(256)
 deep_collect_kernel(const float* __restrict__ tD, const int64_t* __restrict__ tI, int64_t nq, int kk, float* __restrict__ D,
-                    int64_t* __restrict__ I, int k, int off, float* __restrict__ ceilD, int64_t* __restrict__ ceilI) {
+                    int64_t* __restrict__ I, int k, int off, float* __restrict__ ceilD, int64_t* __restrict__ ceilI,
+                    int* __restrict__ ceilN) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t q = gid / kk;
     if (q >= nq) return;
@@ -855,7 +856,20 @@ deep_collect_kernel(const float* __restrict__ tD, const int64_t* __restrict__ tI
     const int64_t id = tI[gid];
     D[q * k + off + i] = sc;
     I[q * k + off + i] = id;
-    if (i == kk - 1) { ceilD[q] = sc; ceilI[q] = id; }
+    if (i == kk - 1) {
+        if (ceilN) {
+            // Merges only (a scan's row ids are distinct): how many copies of the ceiling entry — same score, same
+            // id, e.g. one document present in two shards' lists — have been returned up to here. The next pass
+            // admits the remaining copies (deep_stage_kernel); ResultHeap keeps such duplicates too (reducer.py:16).
+            const uint32_t os = f32_ordered(sc + 0.0f);
+            int c = 1;
+            while (c < kk && tI[gid - c] == id && f32_ordered(tD[gid - c] + 0.0f) == os) ++c;
+            const bool cont = c == kk && off > 0 && ceilI[q] == id && f32_ordered(ceilD[q] + 0.0f) == os;
+            ceilN[q] = (cont ? ceilN[q] : 0) + c;
+        }
+        ceilD[q] = sc;
+        ceilI[q] = id;
+    }
 }
 
 // Stage of a deep merge: S lists of k_in entries per query, any order, cut into chunks of `chunk` entries ->
@@ -865,7 +879,7 @@ deep_collect_kernel(const float* __restrict__ tD, const int64_t* __restrict__ tI
 __global__ void __launch_bounds__(256)
 deep_stage_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, int S, int64_t nq, int k_in, int chunk,
                   int nchunks, int64_t q0, int64_t nb, const float* __restrict__ ceilD, const int64_t* __restrict__ ceilI,
-                  float* __restrict__ sD, int64_t* __restrict__ sI) {
+                  const int* __restrict__ ceilN, int* __restrict__ eqctr, float* __restrict__ sD, int64_t* __restrict__ sI) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t per_list = nb * chunk;
     const int64_t l = gid / per_list;                    // staged list: s * nchunks + c
@@ -884,8 +898,12 @@ deep_stage_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, in
         if (ceilI) {
             const int64_t cid = ceilI[q0 + qb];
             const float csc = ceilD[q0 + qb] + 0.0f;
-            const bool after = cid >= 0 && sc > -FLT_MAX &&
-                               entry_before(f32_ordered(csc), cid, f32_ordered(sc), id);
+            bool after = cid >= 0 && sc > -FLT_MAX &&
+                         entry_before(f32_ordered(csc), cid, f32_ordered(sc), id);
+            // a copy of the ceiling entry itself: ceilN of them were returned already (which ones does not matter,
+            // they are identical), the others are still to come
+            if (!after && cid >= 0 && id == cid && sc > -FLT_MAX && f32_ordered(sc) == f32_ordered(csc))
+                after = atomicAdd(&eqctr[q0 + qb], 1) >= ceilN[q0 + qb];
             if (!after) { sc = -FLT_MAX; id = -1; }
         }
     }

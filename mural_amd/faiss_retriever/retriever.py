@@ -202,7 +202,8 @@ class FlatIPIndex:
         a, b, c = C.c_float(), C.c_int(), C.c_int64()
         _lib.check(_lib.lib().ipx_last_bf16_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"rescore_ms": a.value, "candidates": b.value, "fallback_queries": c.value,
-                "outlier_rows": int(_lib.lib().ipx_outlier_rows(self._h))}
+                "outlier_rows": int(_lib.lib().ipx_outlier_rows(self._h)),
+                "exact_queries": int(_lib.lib().ipx_last_exact_queries(self._h))}
 
     def last_geometry(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()

@@ -51,7 +51,8 @@ def assert_bits(D, I, Q, X, k):
     (20000, 100, 513, 100, 3),        # d not a multiple of 32, three adds, three query blocks
     (9000, 17, 64, 512, 2),           # 4k = 2048 candidates: the longest list
     (9000, 48, 64, 1000, 1),          # hi + lo query parts, 2000 candidates
-    (9000, 48, 64, 1500, 1),          # 2k > limit: storage 1 goes straight to the fp32 scan
+    (9000, 48, 64, 1500, 1),          # 3000 candidates (lists up to 4096 entries: depths up to 2048)
+    (9000, 48, 300, 2048, 2),         # the deepest search the bf16 scan serves, 4096 candidates, large batch
     (777, 768, 1, 100, 1), (255, 16, 257, 5, 1), (257, 16, 256, 300, 1), (1, 8, 3, 4, 1),
 ])
 def test_bf16scan_is_bit_identical_to_the_fp32_scan(R, n, d, nq, k, adds):
@@ -61,7 +62,7 @@ def test_bf16scan_is_bit_identical_to_the_fp32_scan(R, n, d, nq, k, adds):
     assert D.dtype == np.float32 and I.dtype == np.int64 and D.shape == (nq, k) == I.shape
     assert_bits(D, I, Q, X, k)
     st = ix.last_bf16_stats()
-    assert (st["candidates"] > 0) == (2 * k <= 2048)  # depths whose 2k candidates fit take the bf16 scan
+    assert st["candidates"] > 0                        # every depth up to IPX_MAX_K takes the bf16 scan
     # same index, fp32 scan forced: the two scans of one index agree bit for bit
     ix.set_param("f32_scan", 1)
     D2, I2 = ix.search(Q, k)
@@ -325,7 +326,7 @@ def _with_outliers(X, rows, rng, special=True):
     (30000, 768, 32, 100, 3, 12),      # small batch (64-query tile, hi + lo parts), outliers arrive over three adds
     (20000, 100, 513, 10, 2, 40),
     (50000, 64, 70, 1000, 1, 9),       # deep lists
-    (9000, 48, 64, 1500, 1, 9),        # deeper than the bf16 scan serves: the fp32 scan sees the rows itself
+    (9000, 48, 64, 1500, 1, 9),        # 3000 candidates
     (20000, 96, 260, 50, 4, 300),      # more outliers than the side list holds: the rest count as ordinary rows
     (600, 32, 5, 700, 1, 20),          # k > n
 ])
@@ -347,7 +348,7 @@ def test_outlier_rows_are_scored_on_the_side(R, n, d, nq, k, adds, nout):
     assert np.array_equal(I, rI), f"ids differ at {np.argwhere(I != rI)[:3].tolist()}"
     assert np.array_equal(D.view(np.uint32), rD.view(np.uint32)), "score bits differ"
     st = ix.last_bf16_stats()
-    if 2 * k <= 2048 and n > 4000:      # (the small index takes its scale from rows that include the long ones)
+    if n > 4000:                        # (the small index takes its scale from rows that include the long ones)
         assert st["candidates"] > 0 and st["outlier_rows"] == min(nout, 256)
         if nout <= 256 and k <= 100:
             assert st["fallback_queries"] == 0
@@ -356,7 +357,7 @@ def test_outlier_rows_are_scored_on_the_side(R, n, d, nq, k, adds, nout):
     assert np.array_equal(I, I2) and np.array_equal(D.view(np.uint32), D2.view(np.uint32))
     ix.set_param("f32_scan", 0)
     # every large-batch scan kernel skips the NaN copies the same way
-    if nq > 64 and 2 * k <= 2048:
+    if nq > 64:
         for prm in ({"bf16_waves": 8}, {"bf16_pp": 1}, {"bf16_pp": 3}, {"bf16_shape16": 0}, {"query_parts": 2},
                     {"no_small_batch": 1, "max_splits": 1}):
             for key, val in prm.items():
@@ -460,6 +461,103 @@ def test_large_batch_scan_variants_return_the_same_bits(R, n, d, nq, k):
                 assert ix.last_bf16_stats()["candidates"] > 0
                 assert np.array_equal(I, rI), (ms, prm, np.argwhere(I != rI)[:3].tolist())
                 assert np.array_equal(D.view(np.uint32), rD.view(np.uint32)), (ms, prm)
+
+
+def _ramp(n, d, base=0.0, sign=1.0):
+    X = np.zeros((n, d), np.float32)
+    X[:, 0] = (np.float32(base) + np.arange(n, dtype=np.float32)) * np.float32(sign)
+    return X
+
+
+@pytest.mark.parametrize("storage", ["bf16scan", "bf16"])
+def test_inf_row_outside_the_side_list_is_not_lost(R, storage):
+    """Regression for the one failure of round 2's fuzz runs (seed 7, case 114: 2122 ramp rows, 65 queries, hi + lo
+    parts, a list longer than the index). Cause: a row with an inf element that the side list of outlier rows did
+    not take (more than 256 rows qualified; which ones get a slot is decided by an atomic counter, hence
+    'intermittent') is scanned like any other row, and with hi + lo query parts of opposite sign its approximate
+    score is inf * hi + inf * lo = NaN — never admitted — while its exact score is +inf, the best hit. The list was
+    not full, 'holds every admissible row' was taken as proof, and the top hit went missing. Here the order of the
+    adds makes it deterministic: the side list is full before the inf row arrives. Storage 2 has no side list at
+    all: any inf row does it there."""
+    n, d, nq = 2122, 192, 65
+    X = _ramp(n, d)
+    X[1500, 70] = np.inf
+    X[1600, 62] = np.nan
+    X[1700] *= np.float32(1e30)
+    Q = gaussian(4321, (nq, d))
+    hi = bf16_round(Q[:, 70])
+    lo = bf16_round(Q[:, 70] - hi)
+    assert ((Q[:, 70] > 0) & (lo < 0)).sum() >= 5             # queries whose parts cancel on the inf element
+    ix = R.FlatIPIndex(d, storage=storage)
+    ix.add(X[:425])                                           # sets the outlier scale: |x| <= 424
+    ix.add(X[425:1025])                                       # 534 rows beyond it: the 256 slots are taken
+    ix.add(X[1025:])                                          # the inf / NaN / huge rows count as ordinary rows
+    ref = bf16_round(X) if storage == "bf16" else X
+    for k in (100, 1024, 1638) + ((2048,) if storage == "bf16scan" else ()):
+        with np.errstate(all="ignore"):
+            rD, rI = O.topk_total_order(O.scores_mfma_order(Q, ref), k)
+        assert (rI[:, 0] == 1500).sum() >= 5                  # the inf row is the best hit of those queries
+        for parts in (0, 1, 2):
+            for q in (Q, Q[:9]):                              # large-batch and small-batch kernels
+                ix.set_param("query_parts", parts)            # (also clears the index's memory of failed depths)
+                D, I = ix.search(q, k)
+                m = len(q)
+                assert np.array_equal(I, rI[:m]), (k, parts, m, np.argwhere(I != rI[:m])[:3].tolist())
+                assert np.array_equal(D.view(np.uint32), rD[:m].view(np.uint32)), (k, parts, m)
+                st = ix.last_bf16_stats()
+                assert st["candidates"] > 0 and st["exact_queries"] == m      # no bf16 list is trusted here
+
+
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+@pytest.mark.parametrize("n", [2122, 20000])
+def test_repeat_pass_with_the_longest_list_on_ramp_data(R, n, sign):
+    """The repeat pass every flagged query takes — 4096 candidates, hi + lo query parts, the 16-wave kernel — driven
+    deterministically on more than one query block's worth of one 64-query group (65 queries: a full group and a
+    ragged one) over ramp data, whose bf16 copy ties hundreds of rows per value: the first pass is forced to lists of
+    k entries, which cannot pass the margin test, so every query is repeated; with 2122 rows the long list holds the
+    whole index, with 20000 it has to pass the margin test on its own. Depths up to the deepest the bf16 scan
+    serves."""
+    d, nq = 192, 65
+    X = _ramp(n, d, base=40000.0, sign=sign)                  # norms within a factor 1.5: no outlier rows
+    rng = np.random.default_rng(11)
+    Q = (0.02 * rng.standard_normal((nq, d))).astype(np.float32)
+    Q[:, 0] = (1.0 + rng.random(nq) * 2.0) * np.where(rng.random(nq) < 0.5, -1.0, 1.0)
+    for storage, ref in (("bf16scan", X), ("bf16", bf16_round(X))):
+        ix = index(R, X, storage, adds=3)
+        ix.set_param("bf16_candidates", 16)                   # first pass: lists of max(16, k) = k entries
+        for k in (100, 1024, 1638) + ((2048,) if storage == "bf16scan" else ()):
+            rD, rI = O.topk_total_order(O.scores_mfma_order(Q, ref), k)
+            for ms in (0, 5):
+                ix.set_param("max_splits", ms)
+                D, I = ix.search(Q, k)
+                assert np.array_equal(I, rI), (storage, k, ms, np.argwhere(I != rI)[:3].tolist())
+                assert np.array_equal(D.view(np.uint32), rD.view(np.uint32)), (storage, k, ms)
+                st = ix.last_bf16_stats()
+                assert st["candidates"] == k and st["fallback_queries"] == nq          # all repeated ...
+                assert st["exact_queries"] == 0, (storage, k, ms, st)                  # ... and served by the long list
+        assert ix.last_bf16_stats()["outlier_rows"] == 0
+
+
+def test_forced_candidate_count_does_not_lift_depth_limits(R):
+    """`bf16_candidates` changes the list length, never which depths the bf16 scan serves (it once bypassed both
+    checks: k = 5000 with a 4096-entry list read past the list)."""
+    from mural_amd._lib import IpxError
+    X, Q = gaussian(31, (9000, 32)), gaussian(32, (70, 32))
+    ix = index(R, X, "bf16scan")
+    ix.set_param("bf16_candidates", 4096)
+    D, I = ix.search(Q, 5000)
+    assert ix.last_bf16_stats()["candidates"] == 0            # the fp32 scan (deep passes)
+    assert_bits(D, I, Q, X, 5000)
+    D, I = ix.search(Q, 2048)
+    assert ix.last_bf16_stats()["candidates"] == 4096
+    assert_bits(D, I, Q, X, 2048)
+    ix2 = index(R, X, "bf16")
+    ix2.set_param("bf16_candidates", 4096)
+    with pytest.raises(IpxError) as e:
+        ix2.search(Q, 5000)
+    assert e.value.code == 1
+    D, I = ix2.search(Q, 1638)
+    assert_bits(D, I, Q, bf16_round(X), 1638)
 
 
 def test_randomised_differential_cases(R):

@@ -272,6 +272,36 @@ def test_merge_topk_matches_reference(R, S, nq, k_in, k_out):
     assert np.array_equal(oI, rI) and np.array_equal(oD, rD)
 
 
+def test_deep_merge_keeps_duplicate_entries_across_a_pass_boundary(R):
+    """One document in two shards' lists (same score, same id) is returned twice by ResultHeap (reducer.py:15-18) and
+    by the single-pass merge; a merge beyond IPX_MAX_K entries must do the same when its pass boundary (rank 2048,
+    4096, ...) falls between the copies — it once returned the entry a single time there."""
+    rng = np.random.default_rng(12)
+    S, nq, k_in, k_out = 3, 4, 3000, 6000
+    Ds = np.sort(rng.standard_normal((S, nq, k_in)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    Is = rng.permutation(S * nq * k_in).reshape(S, nq, k_in).astype(np.int64)
+    for q in range(nq):
+        order = np.argsort(-Ds[:, q, :].ravel(), kind="stable")
+        # an entry near rank 2047 (the last of pass 1) gets copies in the other shards' lists (written over their tail
+        # entries, far down the order): q = 0, 1: one copy, the pair sits on ranks 2047 / 2048; q = 2: two copies, ranks
+        # 2047..2049; q = 3: the entry of rank 2045 four times more, ranks 2045..2049 (three copies returned by pass 1,
+        # two left for pass 2). Then the entry that ends pass 2 (rank 4095 after the shift) gets one copy.
+        r1, c1 = {0: (2047, 1), 1: (2047, 1), 2: (2047, 2), 3: (2045, 4)}[q]
+        for rank, copies, skip in ((r1, c1, 0), (4095 - c1, 1, 8)):
+            s0, j0 = divmod(int(order[rank]), k_in)
+            for c in range(copies):
+                s1 = (s0 + 1 + c % (S - 1)) % S
+                j1 = k_in - 1 - c - skip
+                Ds[s1, q, j1], Is[s1, q, j1] = Ds[s0, q, j0], Is[s0, q, j0]
+    oD, oI = gpu_merge(Ds, Is, k_out)
+    rD, rI = O.merge_total_order(Ds, Is, k_out)
+    assert np.array_equal(oI, rI), np.argwhere(oI != rI)[:4].tolist()
+    assert np.array_equal(oD, rD)
+    for q in range(nq):                     # the construction holds: copies sit on both sides of ranks 2048 and 4096
+        assert rI[q, 2047] == rI[q, 2048] and rD[q, 2047] == rD[q, 2048]
+        assert rI[q, 4095] == rI[q, 4096] and rD[q, 4095] == rD[q, 4096]
+
+
 def test_merge_equals_result_heap_oracle(R):
     # the faiss ResultHeap restatement keeps the same set; order among exact ties may differ
     rng = np.random.default_rng(3)

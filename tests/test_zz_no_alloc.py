@@ -63,6 +63,23 @@ def test_noalloc_search_equals_search_on_two_calls_in_a_row():
             assert np.array_equal(I.cpu().numpy(), rI) and np.array_equal(D.cpu().numpy().view(np.uint32), rD.view(np.uint32))
         finally:
             L.ipx_destroy(h2)
+        # an index that also keeps a bf16 copy (storage 1): the entry point scans its fp32 rows, same bits
+        h4 = C.c_void_p()
+        _lib.check(L.ipx_create(d, 0, C.byref(h4)))
+        try:
+            _lib.check(L.ipx_set_param(h4, b"storage", 1))
+            _lib.check(L.ipx_add(h4, C.c_void_p(X.data_ptr()), 20000, _lib.IPX_F32, 1, st))
+            free0 = torch.cuda.mem_get_info(dev)[0]
+            rc, D, I = _search(L, h4, "noalloc", Q2, 10, st)
+            _lib.check(rc)
+            _lib.check(L.ipx_check(h4, st))
+            assert torch.cuda.mem_get_info(dev)[0] == free0
+            assert np.array_equal(I.cpu().numpy(), rI) and np.array_equal(D.cpu().numpy().view(np.uint32), rD.view(np.uint32))
+            rc, D0, I0 = _search(L, h4, "search", Q2, 10, st)          # the bf16 scan + rescoring of the same index
+            _lib.check(rc)
+            assert torch.equal(I, I0) and torch.equal(D.view(torch.int32), D0.view(torch.int32))
+        finally:
+            L.ipx_destroy(h4)
         # limits: a clear error, nothing launched
         big = torch.randn((193, d), generator=g, device=dev)
         rc, _, _ = _search(L, h, "noalloc", big, 10, st)
