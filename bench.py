@@ -73,6 +73,172 @@ def kernel_source_hash():
         return hashlib.sha256(f.read()).hexdigest()
 
 
+XGMI_LINK_GBS = 153.0             # same guide: 7 xGMI links per GPU, ~153 GB/s each (point to point)
+
+
+def _fill(torch, dev, ix, rows, d, seed, kind="gauss", sigma=0.5, block=500_000):
+    """Synthetic rows generated on the device and added block by block. kind: gauss | lognormal (row norms spread by
+    exp(sigma * N(0,1)): unnormalised representations) | l2norm (unit rows) | dups (gauss + 40 exact duplicates per block)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    ix.reserve(rows)
+    for lo in range(0, rows, block):
+        x = torch.randn((min(block, rows - lo), d), generator=g, device=dev, dtype=torch.float32)
+        if kind == "lognormal":
+            x *= torch.exp(sigma * torch.randn((x.shape[0], 1), generator=g, device=dev))
+        elif kind == "l2norm":
+            x /= x.norm(dim=1, keepdim=True)
+        elif kind == "dups":
+            x[1000:1040] = x[1000:1001]
+        ix.add(x)
+    torch.cuda.synchronize()
+    return g
+
+
+def _time_search(torch, fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, out
+
+
+def run_cfg4(torch, dev, d, steps=3, n=1_800_000, nq=8192):
+    """BASELINE.json configs[3] on configs[1]'s corpus: MURAL multi-aspect queries (aspect embeddings + logits, fused
+    on the device, modeling/mul_grain.py:97-110) over 1.8M x 768 rows, bf16 MFMA scan + exact fp32 rescoring."""
+    from mural_amd.faiss_retriever.retriever import FlatIPIndex
+    A, k = 3, 100
+    ix = FlatIPIndex(d, device=dev.index, storage="bf16scan")
+    g = _fill(torch, dev, ix, n, d, 2234)
+    E = torch.randn((nq, A, d), generator=g, device=dev, dtype=torch.float32)
+    logits = torch.randn((nq, A), generator=g, device=dev, dtype=torch.float32)
+    ix.set_timing(True)
+    t_bf, (D, I) = _time_search(torch, lambda: ix.search_aspect_device(E, logits, k, logits=True), steps, 1)
+    tm, bf = ix.last_timing(), ix.last_bf16_stats()
+    ix.set_param("f32_scan", 1)
+    t_f32, (D0, I0) = _time_search(torch, lambda: ix.search_aspect_device(E, logits, k, logits=True), 1, 1)
+    tm0 = ix.last_timing()
+    # the reference fuses at encode time (the pickles hold the fused vectors): the same search on pre-fused queries
+    fused = (torch.softmax(logits, dim=1)[:, :, None] * E).sum(1)
+    D1, I1 = ix.search_device(fused, k)
+    torch.cuda.synchronize()
+    ix.set_param("f32_scan", 0)
+    flops = 2.0 * nq * n * d
+    res = {
+        "what": f"BASELINE.json configs[3]: {nq} MURAL multi-aspect queries ([{nq}, {A}, {d}] aspect embeddings + logits, soft-max "
+                f"and weighted sum fused into the query pack on the device) over a {n} x {d} fp32 corpus with a bf16 copy: "
+                f"bf16 MFMA scan + exact fp32 rescoring, top-{k}; compared bitwise with the fp32 scan of the same aspect "
+                f"queries, and with the search on queries pre-fused by torch (fp32 softmax + sum: same ranking up to near-ties)",
+        "queries_per_s": nq / t_bf, "ms_per_step": t_bf * 1e3, "pack_fuse_ms": round(tm["pack_ms"], 3), "scan_ms": tm["scan_ms"],
+        "merge_ms": round(tm["merge_ms"], 3), "rescore_ms": round(bf["rescore_ms"], 3), "candidates": bf["candidates"],
+        "repeated_queries": bf["fallback_queries"],
+        "bit_identical_to_f32_scan": bool(torch.equal(I, I0)) and bool(torch.equal(D.view(torch.int32), D0.view(torch.int32))),
+        "f32_scan_ms_per_step": t_f32 * 1e3, "f32_scan_kernel_ms": tm0["scan_ms"],
+        "prefused_ids_equal_frac": float((I0 == I1).float().mean()),
+        "prefused_max_rel_score_diff": float(((D0 - D1).abs() / D1.abs().clamp_min(1e-30)).max()),
+        "roofline": {"bound": "mfma", "achieved": flops / (tm["scan_ms"] * 1e-3) / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": flops / (tm["scan_ms"] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                     "kernel": "scan_bf16_w16_kernel<1, true>", "flops_per_launch": flops}}
+    del ix
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_projected_8gpu(torch, dev, d, n_total, nq, steps=3):
+    """What one of 8 ranks does per search of the headline workload, measured on this GPU, plus a model of the one
+    collective: NOT a measured 8-GPU number."""
+    from mural_amd import _lib
+    from mural_amd.faiss_retriever.retriever import FlatIPIndex
+    import ctypes as C
+    world = 8
+    rows = n_total // world
+    ix = FlatIPIndex(d, device=dev.index, storage="bf16scan")
+    _fill(torch, dev, ix, rows, d, 1234)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    Q = torch.randn((nq, d), generator=g, device=dev, dtype=torch.float32)
+    ix.set_timing(True)
+    L = _lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    out = {}
+    for k in (100, 1000):
+        block = int(L.ipx_packed_block_bytes(nq, k))
+        mine = torch.empty(block, dtype=torch.uint8, device=dev)
+        I = mine[: nq * k * 8].view(torch.int64).view(nq, k)
+        D = mine[nq * k * 8: nq * k * 12].view(torch.float32).view(nq, k)
+        row = {"block_bytes_per_rank": block}
+        for scan in ("f32", "bf16scan"):
+            ix.set_param("f32_scan", int(scan == "f32"))
+            t, _ = _time_search(torch, lambda: ix.search_device(Q, k, out=(D, I)), steps, 1)
+            row[scan + "_shard_search_ms"] = t * 1e3
+            row[scan + "_scan_kernel_ms"] = ix.last_timing()["scan_ms"]
+        # the merge every rank runs on the gathered blocks: 8 blocks of this shape (this shard's lists, ids shifted per
+        # block as the other shards' id bases would)
+        allb = torch.empty(world * block, dtype=torch.uint8, device=dev)
+        for r in range(world):
+            allb[r * block: (r + 1) * block].copy_(mine)
+            allb[r * block: r * block + nq * k * 8].view(torch.int64).add_(r * rows)
+        oD = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        oI = torch.empty((nq, k), dtype=torch.int64, device=dev)
+
+        def merge():
+            _lib.check(L.ipx_merge_topk_packed(C.c_void_p(allb.data_ptr()), world, nq, k, k, C.c_void_p(oD.data_ptr()),
+                                               C.c_void_p(oI.data_ptr()), dev.index, st))
+        t_merge, _ = _time_search(torch, merge, 10, 2)
+        # xGMI is point to point: each of the 7 peers' blocks arrives over its own link
+        t_gather = block / (XGMI_LINK_GBS * 1e9) + 20e-6
+        row.update({"merge_ms": t_merge * 1e3, "modelled_allgather_ms": t_gather * 1e3})
+        for scan in ("f32", "bf16scan"):
+            total = row[scan + "_shard_search_ms"] * 1e-3 + t_gather + t_merge
+            row[scan + "_projected_queries_per_s"] = nq / total
+            row[scan + "_projected_ms_per_step"] = total * 1e3
+        out[f"top{k}"] = row
+    ix.set_param("f32_scan", 0)
+    del ix
+    torch.cuda.empty_cache()
+    return {"projection": True,
+            "what": f"NOT measured on 8 GPUs. One rank's share of the headline workload measured on this GPU ({rows} of {n_total} rows, "
+                    f"all {nq} queries: search into the packed exchange block) + ipx_merge_topk_packed over 8 such blocks, "
+                    f"measured + the all-gather MODELLED as block bytes / {XGMI_LINK_GBS:.0f} GB/s (each peer's block over its own "
+                    f"xGMI link) + 20 us; sum = projected time per step of the 8-rank job (ranks run the same work in parallel)",
+            "ranks": world, "rows_per_rank": rows, **out}
+
+
+def run_norm_spread(torch, dev, d, rows=1_000_000, nq=6980, k=100, steps=3):
+    """The bf16 scan's margin rule on rows whose norms spread (MURAL representations are unnormalised, SURVEY 8d names an
+    L2-normalised and a duplicates variant too): same rows x queries shape per variant, Gaussian as the yardstick."""
+    from mural_amd.faiss_retriever.retriever import FlatIPIndex
+    res = {"what": f"{rows} x {d} rows, {nq} queries, top-{k}, storage bf16scan: candidates kept, queries sent to the repeat pass / "
+                   f"answered by the fp32 scan, times, bitwise comparison with the fp32 scan of the same index; `vs_gaussian` = "
+                   f"queries/s relative to the Gaussian variant"}
+    base = None
+    for kind in ("gauss", "lognormal", "l2norm", "dups"):
+        ix = FlatIPIndex(d, device=dev.index, storage="bf16scan")
+        g = _fill(torch, dev, ix, rows, d, 3234, kind=kind)
+        Q = torch.randn((nq, d), generator=g, device=dev, dtype=torch.float32)
+        if kind == "l2norm":
+            Q /= Q.norm(dim=1, keepdim=True)
+        ix.set_timing(True)
+        t, (D, I) = _time_search(torch, lambda: ix.search_device(Q, k), steps, 2)
+        tm, bf = ix.last_timing(), ix.last_bf16_stats()
+        ix.set_param("f32_scan", 1)
+        D0, I0 = ix.search_device(Q, k)
+        torch.cuda.synchronize()
+        if base is None:
+            base = nq / t
+        res[kind] = {"queries_per_s": nq / t, "vs_gaussian": (nq / t) / base, "ms_per_step": t * 1e3, "scan_ms": tm["scan_ms"],
+                     "rescore_ms": round(bf["rescore_ms"], 3), "candidates": bf["candidates"], "outlier_rows": bf["outlier_rows"],
+                     "repeated_queries": bf["fallback_queries"], "exact_path_queries": bf["exact_queries"],
+                     "bit_identical": bool(torch.equal(I, I0)) and bool(torch.equal(D.view(torch.int32), D0.view(torch.int32)))}
+        del ix
+        torch.cuda.empty_cache()
+    res["lognormal"]["sigma"] = 0.5
+    return res
+
+
 CFG5_ROWS_PER_RANK = 12_500_000    # BASELINE.json configs[4]: 100M x 768 bf16 over 8 GPUs
 CFG5_BLOCK = 500_000
 
@@ -166,6 +332,9 @@ def main():
     ap.add_argument("--workload", choices=["headline", "cfg5"], default="headline",
                     help="cfg5: only BASELINE.json configs[4] (12.5M x 768 bf16 shard per rank, batches of 1..64 queries)")
     ap.add_argument("--cfg5-rows", type=int, default=CFG5_ROWS_PER_RANK, help="rows per rank of the cfg5 shard")
+    ap.add_argument("--extras-scale", type=float, default=0.0,
+                    help="run extra.cfg4 / projected_8gpu / norm_spread with their row counts scaled by this factor "
+                         "(the full-size default run carries them at scale 1; a reduced --rows run only when asked)")
     args = ap.parse_args()
 
     # stdout carries ONE line, the JSON: libraries that print there (RCCL's version banner at communicator set-up) are
@@ -357,10 +526,18 @@ def main():
         ix.set_param("f32_scan", 0)
         extra["small_batch_f32_rows"] = small32
 
-    if not args.no_extras and (n, d) == (8_800_000, 768):
-        # BASELINE.json configs[4] (its own shard per rank, weak scaling), any number of ranks; the headline index goes first
+    full = (n, d) == (8_800_000, 768)
+    if not args.no_extras and (full or args.extras_scale > 0):
+        # the headline index goes first; then the measurements that build their own (smaller) indexes
         del index, ix
         torch.cuda.empty_cache()
+        if world == 1:
+            sc = args.extras_scale if args.extras_scale > 0 else 1.0
+            extra["cfg4"] = run_cfg4(torch, dev, d, n=int(1_800_000 * sc), nq=max(64, int(8192 * min(1.0, 4 * sc))))
+            extra["projected_8gpu"] = run_projected_8gpu(torch, dev, d, n, nq)
+            extra["norm_spread"] = run_norm_spread(torch, dev, d, rows=int(1_000_000 * sc), nq=nq)
+    if not args.no_extras and full:
+        # BASELINE.json configs[4] (its own shard per rank, weak scaling), any number of ranks
         extra["cfg5"] = run_cfg5(torch, dist, dev, local_rank, rank, world, d, 100, args.cfg5_rows)
 
     if rank == 0:

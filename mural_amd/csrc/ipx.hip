@@ -135,6 +135,12 @@ struct ipx_index {
     // larger norm than the rest widen every query's margin, the bf16 passes are then wasted work, and searches at that
     // depth or beyond go to the fp32 scan directly. Forgotten when rows are added or a parameter changes.
     int bf16_fail_k = INT32_MAX;
+    // What this index's data has taught the automatic list length (rows whose norms spread widen every margin: MURAL
+    // representations are unnormalised): the automatic candidate count is multiplied by kc_boost / 8 after a large batch
+    // that sent more than 1 % of its queries to the repeat pass, and once the longest list is reached large batches
+    // start with hi + lo query parts. Forgotten when rows are added or a parameter changes.
+    int kc_boost = 8;
+    bool parts_boost = false;
     int* hflags = nullptr;               // pinned host copy of a pass's margin flags + the error word
     size_t hflags_n = 0;
     void* pinned = nullptr;          // host staging of ipx_add (two slices)
@@ -1035,6 +1041,8 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
              : ix->storage == 2 ? (small ? std::max(128, k + k / 2) : std::max(256, k + k / 4))
                            : (small ? std::max(128, 2 * k) : std::max(256, k <= 256 ? 3 * k : 2 * k));
     }
+    if (ix->force_kc == 0 && ix->kc_boost > 8) kc = (int)std::min<int64_t>(MAX_KC, (int64_t)kc * ix->kc_boost / 8);
+    if (ix->query_parts == 0 && ix->parts_boost) qparts = 2;
     kc = std::min(std::max(kc, k), MAX_KC);
 
     const float* qf = dq;
@@ -1051,6 +1059,11 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     if (int rc = bf16_pass(ix, qf, nq, k, kc, qparts, dD, dI, st, true, flagged, hard)) return rc;
     const int64_t nfail = (int64_t)(flagged.size() + hard.size());
     ix->last_fallback = nfail;
+    // more than 1 % of a large batch needs a longer list: the next searches of this index start with one
+    if (ix->force_kc == 0 && nq >= 64 && (int64_t)flagged.size() * 100 > nq) {
+        if (kc < MAX_KC) ix->kc_boost = std::min(128, ix->kc_boost + (ix->kc_boost + 3) / 4);    // x1.25: 8, 10, 13, 17, 22, ...
+        else if (qparts == 1 && ix->query_parts == 0) ix->parts_boost = true;
+    }
     // most of a batch failed with a list that is already half the longest one (or for good): the repeat pass would
     // fail too
     const bool hopeless = ix->storage == 1 && nq >= 64 && nfail * 2 > nq && (2 * kc > MAX_KC || hard.size() * 2 > (size_t)nq) &&
@@ -1332,6 +1345,8 @@ int ipx_add(ipx_index* ix, const void* rows, int64_t n, int dtype, int on_device
     IPX_ON_DEVICE(ix->device);
     hipStream_t st = (hipStream_t)stream;
     ix->bf16_fail_k = INT32_MAX;          // new rows, new norm bounds
+    ix->kc_boost = 8;
+    ix->parts_boost = false;
     if (int rc = grow_storage(ix, ix->ntotal + n, st)) return rc;
     const size_t row_bytes = (size_t)ix->d * dtype_size(dtype);
     if (on_device) {
@@ -1630,6 +1645,8 @@ int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k
 int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
     if (!ix || !name) return fail(IPX_ERR_ARG, "set_param: null argument");
     ix->bf16_fail_k = INT32_MAX;
+    ix->kc_boost = 8;
+    ix->parts_boost = false;
     if (!strcmp(name, "max_splits")) {
         if (value < 0 || value > 65536) return fail(IPX_ERR_ARG, "set_param: max_splits outside [0, 65536]");
         ix->max_splits = (int)value;

@@ -147,6 +147,23 @@ class FlatIPIndex:
                                        C.c_void_p(I.ctypes.data), 0, None))
         return D, I
 
+    def search_aspect_device(self, aspect_emb, weights, k, logits=False, out=None):
+        """search_aspect on torch CUDA tensors (aspect_emb [n, A, d], weights [n, A], fp32), stream-ordered;
+        returns CUDA tensors (D, I)."""
+        import torch
+        n, A, d = aspect_emb.shape
+        assert d == self.d and tuple(weights.shape) == (n, A) and k > 0
+        aspect_emb, weights = aspect_emb.contiguous().float(), weights.contiguous().float()
+        if out is None:
+            D = torch.empty((n, k), dtype=torch.float32, device=aspect_emb.device)
+            I = torch.empty((n, k), dtype=torch.int64, device=aspect_emb.device)
+        else:
+            D, I = out
+        _lib.check(_lib.lib().ipx_search_aspect(self._h, C.c_void_p(aspect_emb.data_ptr()), C.c_void_p(weights.data_ptr()),
+                                                A, int(bool(logits)), n, k, C.c_void_p(D.data_ptr()),
+                                                C.c_void_p(I.data_ptr()), 1, _torch_stream(aspect_emb)))
+        return D, I
+
     # ---- MURAL pooler on the device (MULGRAIN_Pooler.forward 'att', modeling/mul_grain.py:97-132) ----
     def _pool_args(self, hidden, weight, bias, begin_id):
         hidden = np.ascontiguousarray(hidden, dtype="float32")

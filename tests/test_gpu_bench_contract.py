@@ -26,7 +26,8 @@ def _bench(*args):
 
 
 def test_headline_line_has_the_contract_keys():
-    j = _bench("--rows", "400000", "--queries", "600", "--steps", "2", "--warmup", "1", "--cpu-sample-rows", "50000")
+    j = _bench("--rows", "400000", "--queries", "600", "--steps", "2", "--warmup", "1", "--cpu-sample-rows", "50000",
+               "--extras-scale", "0.1")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in j, key
@@ -43,6 +44,21 @@ def test_headline_line_has_the_contract_keys():
     assert b["bit_identical_to_f32_scan"] is True and b["roofline"]["bound"] == "mfma"
     assert j["extra"]["depth_1000"]["bit_identical"] is True
     assert {x["queries"] for x in j["extra"]["small_batch_f32_rows"]} == {1, 16, 64}
+    # BASELINE.json configs[3] (aspect queries fused on the device, bf16 scan + rescoring) with its roofline
+    c4 = j["extra"]["cfg4"]
+    assert c4["bit_identical_to_f32_scan"] is True and c4["prefused_ids_equal_frac"] > 0.99 and c4["prefused_max_rel_score_diff"] < 1e-4
+    assert c4["roofline"]["bound"] == "mfma" and c4["roofline"]["peak"] == 2500.0 and c4["queries_per_s"] > 0
+    # the 8-GPU figure is a labelled projection: measured shard step + measured merge + modelled all-gather
+    p8 = j["extra"]["projected_8gpu"]
+    assert p8["projection"] is True and p8["ranks"] == 8 and p8["rows_per_rank"] == 400000 // 8
+    for key in ("top100", "top1000"):
+        r8 = p8[key]
+        tot = r8["f32_shard_search_ms"] + r8["modelled_allgather_ms"] + r8["merge_ms"]
+        assert abs(r8["f32_projected_ms_per_step"] - tot) <= 1e-6 * tot
+        assert abs(r8["modelled_allgather_ms"] - (r8["block_bytes_per_rank"] / 153e9 + 20e-6) * 1e3) < 1e-9
+    ns = j["extra"]["norm_spread"]
+    for kind in ("gauss", "lognormal", "l2norm", "dups"):
+        assert ns[kind]["bit_identical"] is True and ns[kind]["candidates"] > 0, kind
 
 
 def test_cfg5_line():

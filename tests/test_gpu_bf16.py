@@ -538,6 +538,40 @@ def test_repeat_pass_with_the_longest_list_on_ramp_data(R, n, sign):
         assert ix.last_bf16_stats()["outlier_rows"] == 0
 
 
+def test_norm_spread_rows_teach_the_index_a_longer_list(R):
+    """Rows whose norms spread smoothly (log-normal, sigma 1: no clear outliers, thousands of rows beyond the side
+    list's 256 slots) widen every query's margin: the automatic list fails for much of a large batch, the repeat pass
+    serves it — and the index starts the next search with a longer list (x1.25 per lesson) instead of repeating again.
+    Same bits as the fp32 scan of the same index every time (that scan is checked against the oracle elsewhere);
+    unit-norm rows and mildly spread ones need no lesson."""
+    n, d, nq, k = 200_000, 768, 300, 300
+    rng = np.random.default_rng(17)
+    Q = gaussian(18, (nq, d))
+    G = gaussian(19, (n, d))
+    for sigma, learns in ((1.0, True), (0.2, False), (None, False)):
+        X = G / np.linalg.norm(G, axis=1, keepdims=True) if sigma is None else \
+            (G * np.exp(sigma * rng.standard_normal((n, 1)))).astype(np.float32)
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        ix = index(R, X, "bf16scan", adds=2)
+        ix.set_param("f32_scan", 1)
+        rD, rI = ix.search(Q, k)
+        ix.set_param("f32_scan", 0)
+        seen = []
+        for it in range(8):
+            D, I = ix.search(Q, k)
+            assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32)), (sigma, it)
+            st = ix.last_bf16_stats()
+            seen.append((st["candidates"], st["fallback_queries"]))
+        if learns:
+            assert seen[0][1] * 100 > nq and seen[1][0] > seen[0][0], seen      # repeats, then a longer list
+            assert seen[-1][1] * 100 <= nq, seen                                 # the lessons end the repeats
+        else:
+            assert all(c == seen[0][0] and f == 0 for c, f in seen), seen
+        ix.add(X[:10])                                                           # new rows: lessons forgotten
+        ix.search(Q, k)
+        assert ix.last_bf16_stats()["candidates"] == seen[0][0]
+
+
 def test_forced_candidate_count_does_not_lift_depth_limits(R):
     """`bf16_candidates` changes the list length, never which depths the bf16 scan serves (it once bypassed both
     checks: k = 5000 with a 4096-entry list read past the list)."""
