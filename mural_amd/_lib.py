@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libipx.so")
+# IPX_LIB names another build of the same sources next to this file (scripts/: IPX_LIB=libipx_diag.so, the -DIPX_DIAG
+# build with the kernel variants the shipped library does not carry)
+LIB_PATH = os.path.join(_HERE, os.environ.get("IPX_LIB") or "libipx.so")
 
 #: every symbol include/ipx.h declares (tests check the library exports all of them)
 SYMBOLS = [

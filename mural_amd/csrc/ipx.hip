@@ -8,8 +8,15 @@
 #include "ipx_bf16_kernels.h"
 #include "ipx_f32_small_kernels.h"
 #include "ipx_bf16_w16_kernels.h"
+// The default library ships ONE large-batch bf16 scan (the 16-wave kernel, 2-deep ring: 16x16x32 MFMA with one query
+// part, 32x32x16 with hi + lo parts). The kernels and kernel variants that were built to find it and never won — the
+// 8-wave tile, the ping-pong and direct-corpus-operand kernels, deeper rings, issue orders, workgroup maps — only exist
+// in a -DIPX_DIAG build (libipx_diag.so: __graft_entry__.build_diag(), used by scripts/), where the "bf16_*" knobs of
+// ipx_set_param select them.
+#ifdef IPX_DIAG
 #include "ipx_bf16_pp_kernels.h"
 #include "ipx_bf16_dx_kernels.h"
+#endif
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -130,7 +137,8 @@ struct ipx_index {
     bool outl_thr_set = false;
     int n_outliers = 0;                 // as of the last bf16 pass
     DevBuf maxsq, qfused, candD, candI, flags, sel, qsel, selD, selI, poolH, poolW, poolQ;
-    DevBuf deepD, deepI, ceilD, ceilI;   // deep searches: one pass's lists, the next pass's ceilings
+    DevBuf deepD, deepI, ceilD, ceilI;   // searches beyond DEEP_MAX_K: one pass's lists, the next pass's ceilings
+    DevBuf deepK, deepN;                 // deep lists (k > IPX_MAX_K): the splits' unsorted lists and their lengths
     // Smallest depth at which the margin rule sent most of a batch to the fp32 scan (storage 1): a few rows with a far
     // larger norm than the rest widen every query's margin, the bf16 passes are then wasted work, and searches at that
     // depth or beyond go to the fp32 scan directly. Forgotten when rows are added or a parameter changes.
@@ -303,6 +311,19 @@ int grow_storage(ipx_index* ix, int64_t n, hipStream_t st) {
 int dtype_size(int dtype) { return dtype == IPX_F32 ? 4 : 2; }
 
 struct Geometry { int nqb, ntiles, S, R, G, cap; };
+
+// Deep lists: the splits' unsorted lists of every query (ScanParams::deepK / deepN) -> sorted top k_out (dD / dI).
+int launch_deep_finish(ipx_index* ix, int S, int k_list, int k_out, int64_t nq, float* dD, int64_t* dI, hipStream_t st) {
+    const int64_t total = (int64_t)S * k_list;
+    const int P_max = (int)std::min<int64_t>(ipx::DEEP_LDS_KEYS, next_pow2((int)std::min<int64_t>(total, ipx::DEEP_LDS_KEYS)));
+    const int lds = std::max(P_max, 2) * 8 + (S + 1) * 4 + 256 * 4;
+    if (lds > 64 * 1024)
+        IPX_HIP(hipFuncSetAttribute((const void*)ipx::deep_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(ipx::deep_finish_kernel, dim3((unsigned)nq), dim3(1024), lds, st, (const uint64_t*)ix->deepK.p,
+                       (const int*)ix->deepN.p, S, k_list, k_out, std::max(P_max, 2), ix->id_base, dD, dI);
+    IPX_HIP(hipGetLastError());
+    return 0;
+}
 
 // ---- fp32 scan of a small batch (scan_f32_small_kernel: 32 or 64 queries per workgroup, two workgroups per CU):
 // pack -> scan -> merge. Same scores, bit for bit, as the large tile. Geometry, workspace and launch are separate
@@ -728,6 +749,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
         // kernel at the same ring depth; hi + lo parts at depth 1000, whole search: 197 ms with the 2-deep ring, 203
         // with 3, 217 on 8 waves)
         const bool w16 = !small && (ix->bf16_waves == 16 || ix->bf16_waves == 0);
+#ifdef IPX_DIAG
         void (*kern)(const ipx::ScanParams, const int) =
             small ? (qparts == 2 ? ipx::scan_bf16_kernel<1, 2> : ipx::scan_bf16_kernel<1, 1>)
             : w16 ? (qparts == 2 ? ipx::scan_bf16_w16_kernel<2, false>
@@ -749,6 +771,12 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
         if (w16 && w16_ring == 3 && qparts == 1) kern = ipx::scan_bf16_w16_kernel<1, true, 0, false, 3>;
         if (pp) kern = ix->bf16_pp == 2 ? ipx::scan_bf16_pp_kernel<true> : ipx::scan_bf16_pp_kernel<false>;
         if (dx) kern = ix->bf16_pp == 4 ? ipx::scan_bf16_dx_kernel<true> : ipx::scan_bf16_dx_kernel<false>;
+#else
+        // (the knobs that select anything else cannot be set in this build: ipx_set_param)
+        void (*kern)(const ipx::ScanParams, const int) =
+            small ? (qparts == 2 ? ipx::scan_bf16_kernel<1, 2> : ipx::scan_bf16_kernel<1, 1>)
+                  : (qparts == 2 ? ipx::scan_bf16_w16_kernel<2, false, 0, false, 2> : ipx::scan_bf16_w16_kernel<1, true, 0, false, 2>);
+#endif
         IPX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(kern, dim3(G), dim3((pp || dx) ? 512 : w16 ? 1024 : ipx::HTHREADS), lds, st, p, nsortwaves);
     }
@@ -1245,7 +1273,13 @@ void ipx_set_error_(const char* msg) { g_err = msg ? msg : ""; }
 
 const char* ipx_last_error(void) { return g_err.c_str(); }
 
-const char* ipx_version(void) { return "ipx 0.1 gfx950"; }
+const char* ipx_version(void) {
+#ifdef IPX_DIAG
+    return "ipx 0.1 gfx950 diag";
+#else
+    return "ipx 0.1 gfx950";
+#endif
+}
 
 int ipx_device_count(void) {
     int n = 0;
@@ -1307,7 +1341,7 @@ int ipx_destroy(ipx_index* ix) {
     if (ix->Xp) (void)hipFree(ix->Xp);
     if (ix->Xh) (void)hipFree(ix->Xh);
     for (DevBuf* b : {&ix->Qp, &ix->cand, &ix->partD, &ix->partI, &ix->err, &ix->stageIn, &ix->stageQ, &ix->stageW,
-                      &ix->outD, &ix->outI, &ix->trace, &ix->pub, &ix->maxsq, &ix->outl, &ix->olist, &ix->sideD, &ix->sideI, &ix->qfused, &ix->candD, &ix->candI, &ix->deepD, &ix->deepI, &ix->ceilD, &ix->ceilI,
+                      &ix->outD, &ix->outI, &ix->trace, &ix->pub, &ix->maxsq, &ix->outl, &ix->olist, &ix->sideD, &ix->sideI, &ix->qfused, &ix->candD, &ix->candI, &ix->deepD, &ix->deepI, &ix->ceilD, &ix->ceilI, &ix->deepK, &ix->deepN,
                       &ix->flags, &ix->sel, &ix->qsel, &ix->selD, &ix->selI, &ix->poolH, &ix->poolW, &ix->poolQ})
         b->release();
     for (auto& e : ix->ev)
@@ -1670,6 +1704,19 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
         ix->run_tiles = (int)value;
         return 0;
     }
+#ifndef IPX_DIAG
+    {   // kernel variants that only a diagnostic build carries: this build accepts their default values
+        static const struct { const char* name; int64_t dflt, alt; } diag_only[] = {
+            {"bf16_shape16", 1, 1}, {"bf16_pp", 0, 0}, {"bf16_map", 0, 0}, {"bf16_ring", 0, 2}, {"bf16_occ", 1, 1},
+            {"bf16_variant", 0, 0}, {"bf16_waves", 0, 16}};
+        for (const auto& e : diag_only)
+            if (!strcmp(name, e.name)) {
+                if (value == e.dflt || value == e.alt) return 0;
+                return fail(IPX_ERR_ARG, std::string("set_param: ") + name + " selects a kernel variant that only the diagnostic "
+                            "build has (libipx_diag.so, -DIPX_DIAG: __graft_entry__.build_diag())");
+            }
+    }
+#endif
     if (!strcmp(name, "bf16_shape16")) {
         ix->bf16_shape16 = value != 0;
         return 0;

@@ -12,7 +12,7 @@ namespace ipx {
 
 // Entries of a selection's side list per selecting wave (compact_query_select; a wave's scratch is 4 bytes per queue
 // slot + this list).
-constexpr int W16_SEL_AUX = 1024;
+constexpr int W16_SEL_AUX = SEL_AUX;
 
 template <int QP, int NB = 0> struct WCfg {
     static constexpr int THREADS = 1024;
@@ -391,6 +391,17 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
+    if (p.deepK) {           // deep candidate lists: unsorted, deep_finish_kernel selects and sorts across the splits
+        if (wave < nselect) {
+            uint32_t* sh = (uint32_t*)smem + (size_t)wave * (p.cap + W16_SEL_AUX);
+            for (int ql = wave; ql < BQ_; ql += nselect) {
+                const int64_t qglobal = (int64_t)qb * BQ_ + ql;
+                if (qglobal < p.nq)
+                    compact_query_deep_final(p, sh, sh + p.cap, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, qglobal, split);
+            }
+        }
+        return;
+    }
     if (wave < nsortwaves)
         for (int ql = wave; ql < BQ_; ql += nsortwaves) {
             const int64_t qglobal = (int64_t)qb * BQ_ + ql;

@@ -226,7 +226,19 @@ struct ScanParams {
     int map = 0;         // bf16 large-batch scans: query blocks per group of decode_block (0 = query-block-major)
     int nselect = 0;     // scan_bf16_w16_kernel: waves that run the episodes' selections (4 bytes of LDS per queue slot
                          // each; the final sort takes 8: `nsortwaves`); 0 = nsortwaves
+    // Deep lists (k beyond what one wave sorts in LDS: IPX_MAX_K < k <= DEEP_MAX_K; scan_f32_kernel<*, true> and the
+    // 16-wave bf16 scan): a split's final list is not sorted in the kernel — its best k keys go, in any order, to
+    // deepK[(q * S_out + split) * k ...] with their number in deepN[q * S_out + split], and deep_finish_kernel selects
+    // and sorts across the splits.
+    uint64_t* deepK = nullptr;
+    int* deepN = nullptr;
 };
+
+// Side list of a selection (nth_largest_lds) per selecting wave when the scratch is 4 bytes per queue slot.
+constexpr int SEL_AUX = 1024;
+// Deepest list one pass of a scan keeps per query (queue capacity 2 * DEEP_MAX_K slots: one wave's selection scratch,
+// 4 bytes per slot + the side list, is 132 KiB of the CU's 160 KiB LDS).
+constexpr int DEEP_MAX_K = 16384;
 
 // bitonic sort, descending, of P (power of two) 64-bit keys in LDS by one wave
 __device__ __forceinline__ void wave_sort_desc(uint64_t* keys, int P, int lane) {
@@ -458,6 +470,26 @@ __device__ __forceinline__ void compact_query_select(const ScanParams& p, uint64
     wave_lds_sync();
 }
 
+// Final pass of a deep list: the queue's best k keys (all of them if there are fewer), filtered by the threshold like
+// the sorted final pass, go unsorted to the split's slot of deepK. One wave; `sh` / `aux` as in compact_query_select.
+__device__ __forceinline__ void compact_query_deep_final(const ScanParams& p, uint32_t* sh, uint32_t* aux, int* cnts, float* taus,
+                                                         uint64_t* queue, int ql, int lane, int64_t qglobal, int split) {
+    compact_query_select(p, (uint64_t*)sh, cnts, taus, queue, ql, lane, nullptr, aux, SEL_AUX);     // n > k: keep the best k
+    const int n = cnts[ql];
+    const uint32_t cut = f32_ordered(taus[ql]);
+    uint64_t* o = p.deepK + ((size_t)qglobal * p.S_out + split) * p.k;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const uint64_t key = i < n ? queue[i] : 0ull;
+        const bool keep = i < n && (uint32_t)(key >> 32) >= cut;
+        const uint64_t mask = __ballot(keep);
+        if (keep) o[base + __popcll(mask & ((1ull << lane) - 1))] = key;
+        base += __popcll(mask);
+    }
+    if (lane == 0) p.deepN[(size_t)qglobal * p.S_out + split] = base;
+}
+
 // Union threshold. Every split publishes the score of its r-th best hit so far, r = ceil(k/S).
 // Taking the minimum v over the S splits of one query: each split holds >= r rows scoring >= v,
 // so >= S*r >= k rows of the index score >= v and the global k-th best score is >= v. A row
@@ -498,13 +530,16 @@ __device__ __forceinline__ void issue_stage(const ScanParams& p, char* buf, int6
 // pipeline still issues a copy for it, into a buffer nobody reads, so the loop has no branches).
 struct StageCursor { int t, ks; bool ok; };
 
-template <bool CEIL>
+// DEEP: lists beyond IPX_MAX_K entries (ScanParams::deepK): the episodes' selections take 4 bytes of LDS per queue slot
+// + a side list, on p.nselect waves; the final pass writes each split's best k keys unsorted (deep_finish_kernel sorts).
+// The hot loop is the same code; the headline instantiation <false, false> is untouched by it.
+template <bool CEIL, bool DEEP = false>
 __global__ void __launch_bounds__(NTHREADS, 2)
 scan_f32_kernel(const ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [0, 2*STAGE_BYTES) : two K-stage buffers; the same bytes are the sort scratch of a
     // compaction (4 waves x cap keys), which only runs when no stage is live.
-    const int scratch_bytes = 4 * p.cap * 8;
+    const int scratch_bytes = DEEP ? p.nselect * (p.cap + SEL_AUX) * 4 : 4 * p.cap * 8;
     const int stage_region = scratch_bytes > 2 * STAGE_BYTES ? scratch_bytes : 2 * STAGE_BYTES;
     int* cnts = (int*)(smem + stage_region);
     float* taus = (float*)(smem + stage_region + BQ * 4);
@@ -790,9 +825,18 @@ scan_f32_kernel(const ScanParams p) {
             __syncthreads();
             ++n_compact;
             if (tid < 2) flags[tid] = 0;
-            for (int ql = wave; ql < BQ; ql += 4)
-                compact_query_select(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
-                                     mypub ? mypub + ql : nullptr);
+            if constexpr (DEEP) {
+                if (wave < p.nselect) {
+                    uint32_t* sh = (uint32_t*)smem + (size_t)wave * (p.cap + SEL_AUX);
+                    for (int ql = wave; ql < BQ; ql += p.nselect)
+                        compact_query_select(p, (uint64_t*)sh, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
+                                             mypub ? mypub + ql : nullptr, sh + p.cap, SEL_AUX);
+                }
+            } else {
+                for (int ql = wave; ql < BQ; ql += 4)
+                    compact_query_select(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
+                                         mypub ? mypub + ql : nullptr);
+            }
             __syncthreads();
             poll_union_threshold(p, taus, qb, tid);
             issue_stage(p, smem + (g & 1) * STAGE_BYTES, c0.t, qb, c0.ks, wave, lane);
@@ -813,10 +857,21 @@ scan_f32_kernel(const ScanParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tail's dummy copies write LDS too
     __syncthreads();
-    for (int ql = wave; ql < BQ; ql += 4) {
-        const int64_t qglobal = (int64_t)qb * BQ + ql;
-        if (qglobal < p.nq)
-            compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, true, qglobal, split, nullptr);
+    if constexpr (DEEP) {
+        if (wave < p.nselect) {
+            uint32_t* sh = (uint32_t*)smem + (size_t)wave * (p.cap + SEL_AUX);
+            for (int ql = wave; ql < BQ; ql += p.nselect) {
+                const int64_t qglobal = (int64_t)qb * BQ + ql;
+                if (qglobal < p.nq)
+                    compact_query_deep_final(p, sh, sh + p.cap, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, qglobal, split);
+            }
+        }
+    } else {
+        for (int ql = wave; ql < BQ; ql += 4) {
+            const int64_t qglobal = (int64_t)qb * BQ + ql;
+            if (qglobal < p.nq)
+                compact_query(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane, true, qglobal, split, nullptr);
+        }
     }
     // ---- anything left to help with? ----
     if (p.helpers <= 0 || !pick_block()) break;
@@ -1083,6 +1138,95 @@ merge_pool_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, in
         const bool empty = i >= n || pos_[i] == 0;
         outD[q * k_out + i] = empty ? -FLT_MAX : f32_unordered(pos_[i]);
         outI[q * k_out + i] = empty ? -1 : pid[i];
+    }
+}
+
+
+// ---- deep lists: the splits' unsorted best-k lists of one query -> its sorted top k_out ----------------------
+// One workgroup of 1024 per query. keys: [nq][S][k_list] (each split's list in any order, counts[q * S + s] entries,
+// as compact_query_deep_final leaves them). T = all entries of the query. T <= DEEP_LDS_KEYS (the rule: thresholds
+// and the union bound leave a split little beyond its share of the top k): everything is sorted in LDS at once. More:
+// the k_out-th largest key is found first by radix selection over the lists where they lie (8 passes of 8 bits with
+// an LDS histogram), then only the entries at or above it — k_out of them — are gathered and sorted. Keys of a scan
+// are distinct; equal keys (none today) would be taken as often as needed.
+constexpr int DEEP_LDS_KEYS = DEEP_MAX_K;
+
+__global__ void __launch_bounds__(1024)
+deep_finish_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ counts, int S, int k_list, int k_out,
+                   int P_max, int64_t id_base, float* __restrict__ outD, int64_t* __restrict__ outI) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* lk = (uint64_t*)smem;                       // [P_max]
+    int* off = (int*)(lk + P_max);                        // [S + 1]
+    int* hist = off + S + 1;                              // [256]
+    __shared__ uint64_t s_prefix;
+    __shared__ int s_need, s_c1, s_c2;
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    const uint64_t* base = keys + (size_t)q * S * k_list;
+    if (tid == 0) {
+        int acc = 0;
+        for (int s = 0; s < S; ++s) { off[s] = acc; acc += counts[q * S + s]; }
+        off[S] = acc;
+    }
+    __syncthreads();
+    const int T = off[S];
+    auto entry = [&](int e) -> uint64_t {                  // e-th entry of the query, lists concatenated
+        int lo = 0, hi = S - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (off[mid] <= e) lo = mid; else hi = mid - 1; }
+        return base[(size_t)lo * k_list + (e - off[lo])];
+    };
+    int m;                                                 // entries in lk
+    if (T <= P_max) {
+        for (int e = tid; e < T; e += 1024) lk[e] = entry(e);
+        m = T;
+    } else {
+        if (tid == 0) { s_prefix = 0; s_need = k_out; s_c1 = 0; s_c2 = 0; }
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+            __syncthreads();
+            const uint64_t prefix = s_prefix;
+            for (int e = tid; e < T; e += 1024) {
+                const uint64_t key = entry(e);
+                if (shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(int)(key >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int b = 255, acc = 0, need = s_need;
+                while (b > 0 && acc + hist[b] < need) { acc += hist[b]; --b; }
+                s_need = need - acc;
+                s_prefix = prefix | ((uint64_t)b << shift);
+            }
+            __syncthreads();
+        }
+        const uint64_t kth = s_prefix;
+        const int ncopies = s_need;                        // entries equal to kth that belong to the result (>= 1)
+        for (int e = tid; e < T; e += 1024) {
+            const uint64_t key = entry(e);
+            if (key > kth) lk[ncopies + atomicAdd(&s_c1, 1)] = key;
+            else if (key == kth) { const int c = atomicAdd(&s_c2, 1); if (c < ncopies) lk[c] = key; }
+        }
+        m = k_out;
+    }
+    __syncthreads();
+    int P = 2;
+    while (P < m) P <<= 1;
+    for (int i = m + tid; i < P; i += 1024) lk[i] = 0ull;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (P >> 1); i += 1024) {
+                const int lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const uint64_t x = lk[lo], y = lk[hi];
+                if ((x < y) == desc) { lk[lo] = y; lk[hi] = x; }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < k_out; i += 1024) {
+        const uint64_t key = i < m ? lk[i] : 0ull;
+        outD[q * k_out + i] = key ? f32_unordered((uint32_t)(key >> 32)) : -FLT_MAX;
+        outI[q * k_out + i] = key ? id_base + (int64_t)(uint32_t)(~(uint32_t)key) : -1;
     }
 }
 

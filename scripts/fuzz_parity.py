@@ -89,18 +89,24 @@ for c in range(cases):
     if storage != "bf16":
         variants += [("f32 large", {"f32_scan": 1, "no_small_batch": 1}), ("f32 small", {"f32_scan": 1, "small_f32_limit": 100000})]
     if storage != "f32":
-        variants += [("bf16 large", {"no_small_batch": 1}), ("bf16 parts 1", {"query_parts": 1}), ("bf16 parts 2", {"query_parts": 2}),
-                     ("bf16 8 waves", {"no_small_batch": 1, "bf16_waves": 8, "query_parts": int(rng.choice([1, 2]))}),
-                     ("bf16 16 waves", {"no_small_batch": 1, "bf16_waves": 16, "query_parts": int(rng.choice([1, 2])),
-                                        "bf16_shape16": int(rng.choice([0, 1])), "bf16_variant": int(rng.integers(0, 8)),
-                                        "bf16_map": int(rng.choice([0, 1, 2, 3, 7])), "bf16_ring": int(rng.choice([2, 3, 4])),
-                                        "bf16_occ": int(rng.choice([1, 2]))}),
-                     # ping-pong kernels (both operands in LDS / corpus operand straight into registers); shapes they
-                     # do not serve (odd K-stage counts, two query parts) fall back to the 16-wave kernel
-                     ("bf16 ping-pong", {"no_small_batch": 1, "query_parts": 1, "bf16_pp": int(rng.choice([1, 2])),
-                                         "bf16_map": int(rng.choice([0, 1]))}),
-                     ("bf16 direct corpus", {"no_small_batch": 1, "query_parts": 1, "bf16_pp": int(rng.choice([3, 4])),
-                                             "bf16_map": int(rng.choice([0, 2, 5]))})]
+        variants += [("bf16 large", {"no_small_batch": 1}), ("bf16 parts 1", {"query_parts": 1}), ("bf16 parts 2", {"query_parts": 2})]
+        # kernels and variants only a diagnostic build carries (IPX_LIB=libipx_diag.so); the draws are made either way (and in
+        # round 2's order), so a seed generates the same cases on both builds and in old logs
+        diag = [("bf16 8 waves", {"no_small_batch": 1, "bf16_waves": 8, "query_parts": int(rng.choice([1, 2]))}),
+                ("bf16 16 waves", {"no_small_batch": 1, "bf16_waves": 16, "query_parts": int(rng.choice([1, 2])),
+                                   "bf16_shape16": int(rng.choice([0, 1])), "bf16_variant": int(rng.integers(0, 8)),
+                                   "bf16_map": int(rng.choice([0, 1, 2, 3, 7])), "bf16_ring": int(rng.choice([2, 3, 4])),
+                                   "bf16_occ": int(rng.choice([1, 2]))}),
+                # ping-pong kernels (both operands in LDS / corpus operand straight into registers); shapes they
+                # do not serve (odd K-stage counts, two query parts) fall back to the 16-wave kernel
+                ("bf16 ping-pong", {"no_small_batch": 1, "query_parts": 1, "bf16_pp": int(rng.choice([1, 2])),
+                                    "bf16_map": int(rng.choice([0, 1]))}),
+                ("bf16 direct corpus", {"no_small_batch": 1, "query_parts": 1, "bf16_pp": int(rng.choice([3, 4])),
+                                        "bf16_map": int(rng.choice([0, 2, 5]))})]
+        if b"diag" in _lib.lib().ipx_version():
+            variants += diag
+        else:       # the shipped large-batch kernel with the query parts the first diagnostic variant drew
+            variants += [("bf16 large parts", {"no_small_batch": 1, "query_parts": diag[0][1]["query_parts"]})]
     if os.environ.get("ONLY_CASE") and c != int(os.environ["ONLY_CASE"]):      # replay one case of a seed
         del ix
         continue

@@ -30,3 +30,10 @@ def ipx():
 
 def gaussian(seed, shape):
     return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
+
+
+def diag_build():
+    """True when the loaded library is the diagnostic build (-DIPX_DIAG): it also carries the large-batch bf16 kernels
+    and variants the default library does not ship, and the "bf16_*" knobs that select them."""
+    from mural_amd import _lib
+    return b"diag" in _lib.lib().ipx_version()

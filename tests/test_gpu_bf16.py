@@ -9,7 +9,7 @@ sufficiency check of rescore_kernel or is repeated on a longer list / the fp32 s
 import numpy as np
 import pytest
 
-from conftest import gaussian
+from conftest import diag_build, gaussian
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -358,8 +358,10 @@ def test_outlier_rows_are_scored_on_the_side(R, n, d, nq, k, adds, nout):
     ix.set_param("f32_scan", 0)
     # every large-batch scan kernel skips the NaN copies the same way
     if nq > 64:
-        for prm in ({"bf16_waves": 8}, {"bf16_pp": 1}, {"bf16_pp": 3}, {"bf16_shape16": 0}, {"query_parts": 2},
-                    {"no_small_batch": 1, "max_splits": 1}):
+        variants = [{"query_parts": 2}, {"no_small_batch": 1, "max_splits": 1}]
+        if diag_build():
+            variants += [{"bf16_waves": 8}, {"bf16_pp": 1}, {"bf16_pp": 3}, {"bf16_shape16": 0}]
+        for prm in variants:
             for key, val in prm.items():
                 ix.set_param(key, val)
             D3, I3 = ix.search(Q, k)
@@ -439,9 +441,10 @@ def test_short_rows_many_runs_per_workgroup(R, storage, nq):
 @pytest.mark.parametrize("n,d,nq,k", [(60000, 768, 300, 100), (40000, 192, 700, 10), (50000, 64, 257, 100),
                                       (30000, 100, 260, 100), (70000, 384, 70, 256)])
 def test_large_batch_scan_variants_return_the_same_bits(R, n, d, nq, k):
-    """Every large-batch bf16 scan (16 waves in both MFMA shapes and issue orders, 8 waves, the ping-pong kernel, the
-    direct-corpus-operand kernel, ring depths, workgroup mappings) on one index: the same bits as the oracle. Split caps
-    1 / 2 make a workgroup scan many tiles: compaction episodes, pipeline restarts, the split's meeting points."""
+    """Every large-batch bf16 scan the loaded library carries on one index: the same bits as the oracle. The default
+    library has the 16-wave kernel with one and with two query parts; a diagnostic build (-DIPX_DIAG) adds both MFMA
+    shapes and issue orders, 8 waves, the ping-pong kernel, the direct-corpus-operand kernel, ring depths, workgroup
+    mappings. Split caps 1 / 2 make a workgroup scan many tiles: compaction episodes, pipeline restarts."""
     X, Q = gaussian(61, (n, d)), gaussian(62, (nq, d))
     for storage, ref in (("bf16scan", X), ("bf16", bf16_round(X))):
         rD, rI = O.topk_total_order(O.scores_mfma_order(Q, ref), k)      # the oracle once per index, not per variant
@@ -450,12 +453,15 @@ def test_large_batch_scan_variants_return_the_same_bits(R, n, d, nq, k):
         ix.set_param("query_parts", 1)
         for ms in (2, 0, 1):
             ix.set_param("max_splits", ms)
-            for prm in ({}, {"bf16_ring": 3}, {"bf16_ring": 4, "bf16_map": 2}, {"bf16_ring": 2, "bf16_map": 7}, {"bf16_ring": 2, "bf16_occ": 2},
-                        {"bf16_shape16": 0}, {"bf16_shape16": 0, "bf16_variant": 2}, {"bf16_shape16": 0, "bf16_variant": 3},
-                        {"bf16_shape16": 0, "bf16_variant": 5, "bf16_map": 1}, {"bf16_waves": 8}, {"bf16_pp": 1},
-                        {"bf16_pp": 2, "bf16_map": 1}, {"bf16_pp": 3, "bf16_map": 3}, {"bf16_pp": 4}):
+            variants = [{}, {"query_parts": 2}]
+            if diag_build():
+                variants += [{"bf16_ring": 3}, {"bf16_ring": 4, "bf16_map": 2}, {"bf16_ring": 2, "bf16_map": 7}, {"bf16_ring": 2, "bf16_occ": 2},
+                             {"bf16_shape16": 0}, {"bf16_shape16": 0, "bf16_variant": 2}, {"bf16_shape16": 0, "bf16_variant": 3},
+                             {"bf16_shape16": 0, "bf16_variant": 5, "bf16_map": 1}, {"bf16_waves": 8}, {"bf16_pp": 1},
+                             {"bf16_pp": 2, "bf16_map": 1}, {"bf16_pp": 3, "bf16_map": 3}, {"bf16_pp": 4}]
+            for prm in variants:
                 for key, val in {"bf16_shape16": 1, "bf16_variant": 0, "bf16_map": 0, "bf16_waves": 0, "bf16_pp": 0, "bf16_ring": 0,
-                                 "bf16_occ": 1, **prm}.items():
+                                 "bf16_occ": 1, "query_parts": 1, **prm}.items():
                     ix.set_param(key, val)
                 D, I = ix.search(Q, k)
                 assert ix.last_bf16_stats()["candidates"] > 0
