@@ -472,7 +472,11 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
                   const int64_t* ceilI = nullptr) {
     // up to 192 queries: the 32 / 64-query tile does a fraction of the 256-query tile's matrix work
     // (passes of a deep search that carry a ceiling stay on the 256-query kernel, the one that knows ceilings)
-    if (nq <= ix->small_f32_limit && !ix->no_small_batch && !ceilI)
+    // Lists beyond IPX_MAX_K entries (and every pass that carries a ceiling) take the deep form of the kernel: selections
+    // on 4 bytes of LDS per queue slot, the splits' lists left unsorted, deep_finish_kernel behind it.
+    const bool deep = k > IPX_MAX_K || ceilI;
+    if (k > ipx::DEEP_MAX_K) return fail(IPX_ERR_ARG, "search: one pass serves k <= " + std::to_string(ipx::DEEP_MAX_K));
+    if (nq <= ix->small_f32_limit && !ix->no_small_batch && !deep)
         return scan_f32_small_path(ix, dq, dw, A, logits, nq, k, dD, dI, st, primary);
     const bool record = primary && ix->timing;
     const int d = ix->d, nks = ix->nks;
@@ -480,8 +484,15 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
     const size_t nout = (size_t)nq * k;
     const int nqb = (int)((nq + ipx::BQ - 1) / ipx::BQ);
     const int ntiles = (int)((N + ipx::BD - 1) / ipx::BD);
+    const int cap = std::max(512, next_pow2(2 * k));
+    // deep lists: as many selecting waves as fit the LDS of a CU that holds two workgroups (80 KiB each) — or one, when a
+    // single wave's selection scratch is larger than that (k > 8192)
+    const int sel_bytes = (cap + ipx::SEL_AUX) * 4;
+    const int half_cu = 80 * 1024 - ipx::LDS_STATE_BYTES - 64, whole_cu = 160 * 1024 - ipx::LDS_STATE_BYTES - 64;
+    const bool two_per_cu = !deep || sel_bytes <= half_cu;
+    const int nsel = deep ? std::max(1, std::min(4, (two_per_cu ? half_cu : whole_cu) / sel_bytes)) : 0;
     // geometry: (up to) all workgroups resident at once, 2 per CU; S of them share a query block.
-    const int resident = 2 * ix->num_cus;
+    const int resident = (two_per_cu ? 2 : 1) * ix->num_cus;
     // A query block's S workgroups take runs of R corpus tiles from a shared counter.
     int S = std::max(1, resident / nqb);
     if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
@@ -489,16 +500,18 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
     const int R = ix->run_tiles > 0 ? ix->run_tiles : std::max(4, std::min(64, ntiles / (S * 256)));
     const int nruns = (ntiles + R - 1) / R;
     S = std::min(S, nruns);
-    const int cap = std::max(512, next_pow2(2 * k));
     // spare list slots per query block for workgroups that finish their own block early (scan_f32_kernel)
-    const int H = (S > 1 && nqb > 1 && nruns > 4 * S) ? ix->f32_helpers : 0;
+    const int H = (S > 1 && nqb > 1 && nruns > 4 * S && !deep) ? ix->f32_helpers : 0;
     const int S_out = S + H;
     const int G = nqb * S;
 
     if (int rc = ix->Qp.ensure((size_t)nqb * nks * ipx::STAGE_B_BYTES)) return rc;
     if (int rc = ix->cand.ensure((size_t)G * ipx::BQ * cap * sizeof(uint64_t))) return rc;
     if (int rc = ix->err.ensure(256)) return rc;
-    if (S > 1) {
+    if (deep) {
+        if (int rc = ix->deepK.ensure(nout * S_out * sizeof(uint64_t))) return rc;
+        if (int rc = ix->deepN.ensure((size_t)nq * S_out * sizeof(int))) return rc;
+    } else if (S > 1) {
         if (int rc = ix->partD.ensure(nout * S_out * sizeof(float))) return rc;
         if (int rc = ix->partI.ensure(nout * S_out * sizeof(int64_t))) return rc;
     }
@@ -551,15 +564,27 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
     }
     p.ceilD = ceilD;
     p.ceilI = ceilI;
-    const int lds = std::max(2 * ipx::STAGE_BYTES, 4 * cap * 8) + ipx::LDS_STATE_BYTES;
-    void (*kern)(const ipx::ScanParams) = ceilI ? ipx::scan_f32_kernel<true> : ipx::scan_f32_kernel<false>;
+    p.nselect = nsel;
+    if (deep) {
+        p.deepK = (uint64_t*)ix->deepK.p;
+        p.deepN = (int*)ix->deepN.p;
+    }
+    const int lds = std::max(2 * ipx::STAGE_BYTES, deep ? nsel * sel_bytes : 4 * cap * 8) + ipx::LDS_STATE_BYTES;
+    void (*kern)(const ipx::ScanParams) = !deep ? ipx::scan_f32_kernel<false, false>
+                                          : ceilI ? ipx::scan_f32_kernel<true, true> : ipx::scan_f32_kernel<false, true>;
     if (lds > 64 * 1024)
         IPX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, dim3(G), dim3(ipx::NTHREADS), lds, st, p);
     IPX_HIP(hipGetLastError());
     if (record) IPX_HIP(hipEventRecord(ix->ev[2], st));
 
-    if (S > 1) {
+    if (deep) {
+        if (int rc = launch_deep_finish(ix, S_out, k, k, nq, dD, dI, st)) return rc;
+        if (record) {
+            IPX_HIP(hipEventRecord(ix->ev[3], st));
+            ix->ev_merge = true;
+        }
+    } else if (S > 1) {
         const int P = next_pow2(k);
         const int mlds = P * 24;
         if (mlds > 64 * 1024)
@@ -596,9 +621,9 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
     return 0;
 }
 
-// k beyond IPX_MAX_K (faiss.IndexFlatIP.search takes any k, reference retriever.py:19): one fp32 scan per
-// IPX_MAX_K ranks. Pass j admits only hits strictly after the last hit of pass j-1 in the result order (score
-// descending, row ascending), so its top list is ranks [j * IPX_MAX_K, ...) of the one total order: the
+// k beyond DEEP_MAX_K (faiss.IndexFlatIP.search takes any k, reference retriever.py:19): one fp32 scan per
+// DEEP_MAX_K ranks. Pass j admits only hits strictly after the last hit of pass j-1 in the result order (score
+// descending, row ascending), so its top list is ranks [j * DEEP_MAX_K, ...) of the one total order: the
 // concatenation is bit for bit what a single pass of depth k would return. Ranks beyond ntotal are (-FLT_MAX, -1)
 // without a scan. HIP events (ipx_set_timing) cover the first pass.
 int scan_f32_deep(ipx_index* ix, const float* dq, const float* dw, int A, int logits, int64_t nq, int k,
@@ -609,7 +634,7 @@ int scan_f32_deep(ipx_index* ix, const float* dq, const float* dw, int A, int lo
         hipLaunchKernelGGL(ipx::fill_empty_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, dD, dI, nout);
         IPX_HIP(hipGetLastError());
     }
-    const int step = IPX_MAX_K;
+    const int step = ipx::DEEP_MAX_K;
     if (int rc = ix->deepD.ensure((size_t)nq * step * sizeof(float))) return rc;
     if (int rc = ix->deepI.ensure((size_t)nq * step * sizeof(int64_t))) return rc;
     if (int rc = ix->ceilD.ensure((size_t)nq * sizeof(float))) return rc;
@@ -647,23 +672,25 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     const size_t ncand = (size_t)nq * kc;
     const bool timing = primary && ix->timing;
 
+    // candidate lists beyond MAX_KC entries: the 16-wave kernel with its lists left unsorted + deep_finish_kernel
+    const bool deep = kc > 4096;
     // up to 64 queries: the 64-query variant (a quarter of the MFMA work per corpus byte)
-    const bool small = nq <= 64 && !ix->no_small_batch;
+    const bool small = nq <= 64 && !ix->no_small_batch && !deep;
     const int bq = small ? 64 : 256;
     const int stage_b = bq * 64 * qparts;
     const int nqb = (int)((nq + bq - 1) / bq);
     const int ntiles = (int)((N + ipx::HBD - 1) / ipx::HBD);
     // large batches, one query part: the 16-wave kernel, whose ring depth (and with a 64-KiB ring its workgroups per
     // CU) can be chosen
-    const bool w16_1 = !small && ix->bf16_pp == 0 &&
+    const bool w16_1 = !small && (deep || (ix->bf16_pp == 0 &&
                        ((qparts == 1 && (ix->bf16_waves == 16 || ix->bf16_waves == 0) && ix->bf16_shape16) ||
-                        (qparts == 2 && (ix->bf16_waves == 16 || ix->bf16_waves == 0)));
+                        (qparts == 2 && (ix->bf16_waves == 16 || ix->bf16_waves == 0)))));
     // Ring depth. Two stages (one in flight) measured fastest on the 8.8M x 768 x 6980-query workload: 84 ms against
     // 93 ms with four — the workgroups that stream the same corpus split then keep each other in step through L2
     // (a workgroup that runs ahead misses L2 and waits on HBM, its followers hit), L2 fetch traffic per launch
     // halves (396 -> 170-190 GB) and the chip holds 2.06 instead of 1.82 GHz.
-    const int w16_ring = w16_1 && ix->bf16_ring != 4 ? ix->bf16_ring : 0;   // 0 = the four-deep ring of WCfg
-    const int occ = (w16_ring == 2 && qparts == 1 && ix->bf16_occ == 2) ? 2 : 1;
+    const int w16_ring = deep ? 2 : w16_1 && ix->bf16_ring != 4 ? ix->bf16_ring : 0;   // 0 = the four-deep ring of WCfg
+    const int occ = (w16_ring == 2 && qparts == 1 && ix->bf16_occ == 2 && !deep) ? 2 : 1;
     const int resident = occ * ix->num_cus;                 // one workgroup per CU (two with the 64-KiB ring, if asked)
     int S = std::max(1, resident / nqb);
     if (ix->max_splits > 0) S = std::min(S, ix->max_splits);
@@ -672,7 +699,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     const int nruns = (ntiles + R - 1) / R;
     S = std::min(S, nruns);
     const int G = nqb * S;
-    const bool w16k = !small && (ix->bf16_waves == 16 || ix->bf16_waves == 0) && ix->bf16_pp == 0;
+    const bool w16k = !small && (deep || ((ix->bf16_waves == 16 || ix->bf16_waves == 0) && ix->bf16_pp == 0));
     // queue: kc survivors of a compaction + 2 tiles of appends before the next one runs + room to fill, rounded up to a
     // power of two (a capacity cut to the next multiple of 512 was measured at kc = 3000: 5120 instead of 8192 slots
     // gives the selections two more waves but forces extra episodes — 176 vs 146 ms of scan)
@@ -685,7 +712,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     // LDS for the episodes: the stage ring's bytes, or for the 16-wave kernel (one workgroup per CU, so the CU's LDS
     // is its own) 157 KiB whatever the ring depth
     const int sort_bytes = w16k && occ == 1 ? std::max(ring, 157 * 1024) : ring;
-    const int nsortwaves = std::max(1, std::min(8, sort_bytes / (cap_sort * 8)));
+    const int nsortwaves = deep ? 0 : std::max(1, std::min(8, sort_bytes / (cap_sort * 8)));
     const int nselect = w16k ? std::max(1, std::min(16, sort_bytes / ((cap + ipx::W16_SEL_AUX) * 4))) : 0;
 
     if (int rc = ix->Qp.ensure((size_t)nqb * nks * stage_b)) return rc;
@@ -694,7 +721,10 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     if (int rc = ix->candD.ensure(ncand * sizeof(float))) return rc;
     if (int rc = ix->candI.ensure(ncand * sizeof(int64_t))) return rc;
     if (int rc = ix->flags.ensure((size_t)(nq + 2) * sizeof(int))) return rc;      // + the error word, the outlier count
-    if (S > 1) {
+    if (deep) {
+        if (int rc = ix->deepK.ensure(ncand * S * sizeof(uint64_t))) return rc;
+        if (int rc = ix->deepN.ensure((size_t)nq * S * sizeof(int))) return rc;
+    } else if (S > 1) {
         if (int rc = ix->partD.ensure(ncand * S * sizeof(float))) return rc;
         if (int rc = ix->partI.ensure(ncand * S * sizeof(int64_t))) return rc;
     }
@@ -707,8 +737,8 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
 
     // large batches, one query part: the ping-pong kernels (both operands in LDS: any even number of K-stages;
     // corpus operand straight into registers: a multiple of 6)
-    const bool pp = !small && qparts == 1 && (ix->bf16_pp == 1 || ix->bf16_pp == 2) && (nks & 1) == 0;
-    const bool dx = !small && qparts == 1 && (ix->bf16_pp == 3 || ix->bf16_pp == 4) && nks % 6 == 0;
+    const bool pp = !small && !deep && qparts == 1 && (ix->bf16_pp == 1 || ix->bf16_pp == 2) && (nks & 1) == 0;
+    const bool dx = !small && !deep && qparts == 1 && (ix->bf16_pp == 3 || ix->bf16_pp == 4) && nks % 6 == 0;
     if (timing) IPX_HIP(hipEventRecord(ix->ev[0], st));
     if (int rc = launch_pack_bf16(qf, IPX_F32, nq, (int64_t)nqb * bq, d, (uint16_t*)ix->Qp.p, 0, bq, nks, qparts, st, dx ? 1 : 0)) return rc;
     if (timing) IPX_HIP(hipEventRecord(ix->ev[1], st));
@@ -743,12 +773,16 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     p.ntiles = ntiles;
     p.map = small ? 0 : ix->bf16_map == 1 ? nqb : ix->bf16_map;      // 1 = one group of all query blocks
     p.nselect = nselect;
+    if (deep) {
+        p.deepK = (uint64_t*)ix->deepK.p;
+        p.deepN = (int*)ix->deepN.p;
+    }
     const int lds = std::max({ring, nsortwaves * cap_sort * 8, nselect * (cap + ipx::W16_SEL_AUX) * 4}) + ipx::LDS_STATE_BYTES;
     {
         // large batches: the 16-wave kernel (8.8M x 768, 6980 queries, one query part: 93 vs 102 ms for the 8-wave
         // kernel at the same ring depth; hi + lo parts at depth 1000, whole search: 197 ms with the 2-deep ring, 203
         // with 3, 217 on 8 waves)
-        const bool w16 = !small && (ix->bf16_waves == 16 || ix->bf16_waves == 0);
+        const bool w16 = !small && (deep || ix->bf16_waves == 16 || ix->bf16_waves == 0);
 #ifdef IPX_DIAG
         void (*kern)(const ipx::ScanParams, const int) =
             small ? (qparts == 2 ? ipx::scan_bf16_kernel<1, 2> : ipx::scan_bf16_kernel<1, 1>)
@@ -767,7 +801,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
                 default: break;
             }
         }
-        if (w16 && w16_ring == 2) kern = qparts == 2 ? ipx::scan_bf16_w16_kernel<2, false, 0, false, 2> : ipx::scan_bf16_w16_kernel<1, true, 0, false, 2>;
+        if (deep || (w16 && w16_ring == 2)) kern = qparts == 2 ? ipx::scan_bf16_w16_kernel<2, false, 0, false, 2> : ipx::scan_bf16_w16_kernel<1, true, 0, false, 2>;
         if (w16 && w16_ring == 3 && qparts == 1) kern = ipx::scan_bf16_w16_kernel<1, true, 0, false, 3>;
         if (pp) kern = ix->bf16_pp == 2 ? ipx::scan_bf16_pp_kernel<true> : ipx::scan_bf16_pp_kernel<false>;
         if (dx) kern = ix->bf16_pp == 4 ? ipx::scan_bf16_dx_kernel<true> : ipx::scan_bf16_dx_kernel<false>;
@@ -783,7 +817,9 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     IPX_HIP(hipGetLastError());
     if (timing) IPX_HIP(hipEventRecord(ix->ev[2], st));
 
-    if (S > 1) {
+    if (deep) {
+        if (int rc = launch_deep_finish(ix, S, kc, kc, nq, (float*)ix->candD.p, (int64_t*)ix->candI.p, st)) return rc;
+    } else if (S > 1) {
         const int P = next_pow2(kc);
         const int mlds = P * 24;
         if (mlds > 64 * 1024)
@@ -899,12 +935,14 @@ int redo_queries(ipx_index* ix, const float* qf, const std::vector<int>& sel, in
     return 0;
 }
 
+int merge_deep(const float* dD, const int64_t* dI, int S, int64_t nq, int k_in, int k_out, float* oD, int64_t* oI, hipStream_t st);
+
 // Last resort of an index without fp32 rows (storage 2): queries whose near-ties outnumber the longest candidate
 // list (thousands of duplicate rows at the top, say) get the exact score of EVERY stored row — the rescoring kernel
 // over lists that enumerate the index, IPX_MAX_K rows per list, then one merge of the lists' top-k. Slow (a full
 // pass of scalar fmaf chains per query: milliseconds per million rows) and exact; one query at a time.
 int exact_rows_path(ipx_index* ix, const float* qf, const std::vector<int>& sel, int k, float* dD, int64_t* dI, hipStream_t st) {
-    const int kc = IPX_MAX_K;
+    const int kc = k > IPX_MAX_K ? ipx::DEEP_MAX_K : IPX_MAX_K;       // rows per list (>= k)
     const int64_t N = ix->ntotal;
     const int64_t nlists = (N + kc - 1) / kc, total = nlists * kc;
     if (nlists > 0x7fffffffLL) return fail(IPX_ERR_ARG, "search: index too large for the exact pass");
@@ -947,13 +985,19 @@ int exact_rows_path(ipx_index* ix, const float* qf, const std::vector<int>& sel,
     if (rlds > 64 * 1024)
         IPX_HIP(hipFuncSetAttribute((const void*)ipx::rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rlds));
     const int P = next_pow2(k), mlds = P * 24;
-    if (mlds > 64 * 1024)
+    if (mlds > 64 * 1024 && k <= IPX_MAX_K)
         IPX_HIP(hipFuncSetAttribute((const void*)ipx::merge_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mlds));
     for (int f : sel) {
         IPX_HIP(hipMemsetD32Async((hipDeviceptr_t)ix->sel.p, f, (size_t)nlists, st));
         hipLaunchKernelGGL(ipx::rescore_kernel, dim3((unsigned)nlists), dim3(256), rlds, st, rp);
         IPX_HIP(hipGetLastError());
         // the lists' top-k (sorted) -> row f of the result
+        if (k > IPX_MAX_K) {
+            if (int rc = merge_deep((const float*)ix->partD.p, (const int64_t*)ix->partI.p, (int)nlists, 1, k, k,
+                                    dD + (size_t)f * k, dI + (size_t)f * k, st))
+                return rc;
+            continue;
+        }
         hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3(1), dim3(256), mlds, st, (const float*)ix->partD.p,
                            (const int64_t*)ix->partI.p, (int)nlists, (int64_t)1, k, k, P, 1, (int64_t)k, (int64_t)0,
                            dD + (size_t)f * k, dI + (size_t)f * k, (const int*)nullptr, (int64_t)0);
@@ -1004,6 +1048,8 @@ int merge_outlier_rows(ipx_index* ix, const float* qf, int64_t nq, int k, float*
         IPX_HIP(hipFuncSetAttribute((const void*)ipx::rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rlds));
     hipLaunchKernelGGL(ipx::rescore_kernel, dim3((unsigned)nq), dim3(256), rlds, st, rp);
     IPX_HIP(hipGetLastError());
+    if (k > IPX_MAX_K)       // lists beyond one LDS sort: the two blocks [2][nq][k] through the deep merge
+        return merge_deep((const float*)ix->sideD.p, (const int64_t*)ix->sideI.p, 2, nq, k, k, dD, dI, st);
     const int P = next_pow2(k), mlds = P * 24;
     if (mlds > 64 * 1024)
         IPX_HIP(hipFuncSetAttribute((const void*)ipx::merge_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mlds));
@@ -1069,9 +1115,12 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
              : ix->storage == 2 ? (small ? std::max(128, k + k / 2) : std::max(256, k + k / 4))
                            : (small ? std::max(128, 2 * k) : std::max(256, k <= 256 ? 3 * k : 2 * k));
     }
-    if (ix->force_kc == 0 && ix->kc_boost > 8) kc = (int)std::min<int64_t>(MAX_KC, (int64_t)kc * ix->kc_boost / 8);
+    if (ix->force_kc == 0 && ix->kc_boost > 8) kc = (int)std::min<int64_t>(ipx::DEEP_MAX_K, (int64_t)kc * ix->kc_boost / 8);
     if (ix->query_parts == 0 && ix->parts_boost) qparts = 2;
-    kc = std::min(std::max(kc, k), MAX_KC);
+    // the longest list: MAX_KC for depths one LDS sort serves, DEEP_MAX_K beyond (lists left unsorted by the scan,
+    // deep_finish_kernel; large-batch kernel only)
+    const int kc_max = k > IPX_MAX_K ? ipx::DEEP_MAX_K : MAX_KC;
+    kc = std::min(std::max(kc, k), kc_max);
 
     const float* qf = dq;
     if (A > 0) {   // the fused fp32 query is needed row-major for the rescoring
@@ -1089,18 +1138,18 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     ix->last_fallback = nfail;
     // more than 1 % of a large batch needs a longer list: the next searches of this index start with one
     if (ix->force_kc == 0 && nq >= 64 && (int64_t)flagged.size() * 100 > nq) {
-        if (kc < MAX_KC) ix->kc_boost = std::min(128, ix->kc_boost + (ix->kc_boost + 3) / 4);    // x1.25: 8, 10, 13, 17, 22, ...
+        if (kc < kc_max) ix->kc_boost = std::min(128, ix->kc_boost + (ix->kc_boost + 3) / 4);    // x1.25: 8, 10, 13, 17, 22, ...
         else if (qparts == 1 && ix->query_parts == 0) ix->parts_boost = true;
     }
     // most of a batch failed with a list that is already half the longest one (or for good): the repeat pass would
     // fail too
-    const bool hopeless = ix->storage == 1 && nq >= 64 && nfail * 2 > nq && (2 * kc > MAX_KC || hard.size() * 2 > (size_t)nq) &&
+    const bool hopeless = ix->storage == 1 && nq >= 64 && nfail * 2 > nq && (2 * kc > kc_max || hard.size() * 2 > (size_t)nq) &&
                           ix->force_kc == 0;
     if (hopeless) ix->bf16_fail_k = std::min(ix->bf16_fail_k, k);
-    if (!flagged.empty() && !hopeless && (kc < MAX_KC || qparts == 1)) {    // longest list, hi + lo query
+    if (!flagged.empty() && !hopeless && (kc < kc_max || qparts == 1)) {    // longest list, hi + lo query
         std::vector<int> still, still_hard;
         int rc = redo_queries(ix, qf, flagged, k, dD, dI, st, [&](const float* q2, int64_t n2, float* D2, int64_t* I2) {
-            return bf16_pass(ix, q2, n2, k, MAX_KC, 2, D2, I2, st, false, still, still_hard);
+            return bf16_pass(ix, q2, n2, k, kc_max, 2, D2, I2, st, false, still, still_hard);
         });
         if (rc) return rc;
         still.insert(still.end(), still_hard.begin(), still_hard.end());
@@ -1176,17 +1225,24 @@ int search_impl(ipx_index* ix, const float* q_src, const float* w, int A, int lo
     } else {
         // the error word exists since ipx_create and is cleared whenever it was found set: no fill per search
         ix->last_err = (int*)ix->err.p;
-        // bf16 scan whenever the index keeps a bf16 copy and the depth is one its candidate lists can serve (2k
-        // candidates on fp32 rows, 1.25k on bf16 rows, at most MAX_KC); deeper searches take the fp32 scan, which
-        // bf16-only storage does not have. A forced candidate count ("bf16_candidates") changes the list length,
-        // never these limits.
-        if (ix->storage == 2 && k > IPX_MAX_K * 4 / 5)
-            return fail(IPX_ERR_ARG, "search: bf16 storage serves k <= " + std::to_string(IPX_MAX_K * 4 / 5) +
-                        " (the candidate list is 1.25 k); use storage 0 or 1 for deeper searches");
+        // bf16 scan whenever the index keeps a bf16 copy and the depth is one its candidate lists can serve: 2k
+        // candidates on fp32 rows, 1.75k on bf16 rows, at most DEEP_MAX_K entries (and, for lists beyond MAX_KC, a row
+        // short enough for the rescoring kernel's LDS: d <= 2048). Deeper searches take the fp32 scan, which bf16-only
+        // storage does not have. A forced candidate count ("bf16_candidates") changes the list length, never these
+        // limits.
+        const int bf16_max_k = ipx::DEEP_MAX_K / 2;
+        const bool deep_rows_fit = (ix->storage == 2 ? ix->nks_h * 32 : ix->nks * 16) <= 2048;
+        const int bf16_limit = deep_rows_fit ? bf16_max_k : IPX_MAX_K * 4 / 5;
+        if (ix->storage == 2 && k > bf16_limit)
+            return fail(IPX_ERR_ARG, "search: bf16 storage serves k <= " + std::to_string(bf16_limit) +
+                        (deep_rows_fit ? "" : " at this row length (d > 2048)") +
+                        " (candidate lists of 1.75 k entries, at most " + std::to_string(ipx::DEEP_MAX_K) +
+                        "); use storage 0 or 1 for deeper searches");
         const bool bf16 = ix->storage == 2 ||
-                          (ix->storage == 1 && !ix->force_f32_scan && k <= IPX_MAX_K && k < ix->bf16_fail_k);
+                          (ix->storage == 1 && !ix->force_f32_scan && k <= (deep_rows_fit ? bf16_max_k : IPX_MAX_K) &&
+                           k < ix->bf16_fail_k);
         int rc = bf16 ? scan_bf16_path(ix, dq, dw, A, logits, nq, k, dD, dI, st)
-                 : k > IPX_MAX_K ? scan_f32_deep(ix, dq, dw, A, logits, nq, k, dD, dI, st)
+                 : k > ipx::DEEP_MAX_K ? scan_f32_deep(ix, dq, dw, A, logits, nq, k, dD, dI, st)
                                  : scan_f32_path(ix, dq, dw, A, logits, nq, k, dD, dI, st, true);
         if (rc) return rc;
     }
@@ -1774,7 +1830,8 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
         return 0;
     }
     if (!strcmp(name, "bf16_candidates")) {
-        if (value < 0 || value > 4096) return fail(IPX_ERR_ARG, "set_param: bf16_candidates outside [0, 4096]");
+        if (value < 0 || value > ipx::DEEP_MAX_K)
+            return fail(IPX_ERR_ARG, "set_param: bf16_candidates outside [0, " + std::to_string(ipx::DEEP_MAX_K) + "]");
         ix->force_kc = (int)value;
         return 0;
     }

@@ -191,13 +191,42 @@ def test_bf16scan_aspect_queries_and_float16_rows(R):
 
 def test_depth_limits_of_the_bf16_storage(R):
     from mural_amd._lib import IpxError
-    X, Q = gaussian(31, (6000, 32)), gaussian(32, (10, 32))
+    X, Q = gaussian(31, (20000, 32)), gaussian(32, (10, 32))
     ix = index(R, X, "bf16")
-    D, I = ix.search(Q, 1638)
-    assert_bits(D, I, Q, bf16_round(X), 1638)
+    for k in (1638, 1639, 2048, 2049, 8192):       # lists beyond 4096 entries are left unsorted by the scan (deep lists)
+        D, I = ix.search(Q, k)
+        assert_bits(D, I, Q, bf16_round(X), k)
     with pytest.raises(IpxError) as e:
-        ix.search(Q, 1639)
+        ix.search(Q, 8193)
+    assert e.value.code == 1 and "8192" in str(e.value)
+    # very long rows: the rescoring kernel's LDS holds the query and a list of at most 4096 entries
+    Xl = gaussian(33, (300, 4096))
+    il = index(R, Xl, "bf16")
+    D, I = il.search(gaussian(34, (3, 4096)), 1638)
+    assert (I[:, 300:] == -1).all()
+    with pytest.raises(IpxError) as e:
+        il.search(gaussian(34, (3, 4096)), 1639)
     assert e.value.code == 1 and "1638" in str(e.value)
+
+
+@pytest.mark.parametrize("storage", ["bf16scan", "bf16"])
+@pytest.mark.parametrize("n,d,nq,k", [(30000, 64, 70, 3000), (30000, 64, 300, 5000), (20000, 48, 9, 8192), (3000, 32, 70, 5000)])
+def test_deep_candidate_lists_on_the_bf16_scan(R, storage, n, d, nq, k):
+    """Depths beyond IPX_MAX_K from the bf16 scan: candidate lists of up to 16384 entries, kept unsorted per split and
+    selected + sorted across the splits by deep_finish_kernel, then rescored exactly — the same bits as the oracle
+    (and as the fp32 scan's deep one-pass lists), with one and two query parts, several splits and a single one."""
+    X, Q = gaussian(91, (n, d)), gaussian(92, (nq, d))
+    ref = bf16_round(X) if storage == "bf16" else X
+    rD, rI = O.topk_total_order(O.scores_mfma_order(Q, ref), k)
+    ix = index(R, X, storage, adds=2)
+    for prm in ({}, {"query_parts": 2}, {"max_splits": 1}, {"max_splits": 3, "bf16_candidates": k + 7}):
+        for key, val in {"query_parts": 0, "max_splits": 0, "bf16_candidates": 0, **prm}.items():
+            ix.set_param(key, val)
+        D, I = ix.search(Q, k)
+        st = ix.last_bf16_stats()
+        assert st["candidates"] >= k, (prm, st)
+        assert np.array_equal(I, rI), (prm, st, np.argwhere(I != rI)[:3].tolist())
+        assert np.array_equal(D.view(np.uint32), rD.view(np.uint32)), prm
 
 
 def test_storage_can_only_be_chosen_on_an_empty_index(R):
@@ -580,13 +609,16 @@ def test_norm_spread_rows_teach_the_index_a_longer_list(R):
 
 def test_forced_candidate_count_does_not_lift_depth_limits(R):
     """`bf16_candidates` changes the list length, never which depths the bf16 scan serves (it once bypassed both
-    checks: k = 5000 with a 4096-entry list read past the list)."""
+    checks: a depth beyond the longest list read past the list)."""
     from mural_amd._lib import IpxError
-    X, Q = gaussian(31, (9000, 32)), gaussian(32, (70, 32))
+    X, Q = gaussian(31, (20000, 32)), gaussian(32, (70, 32))
     ix = index(R, X, "bf16scan")
     ix.set_param("bf16_candidates", 4096)
+    D, I = ix.search(Q, 9000)
+    assert ix.last_bf16_stats()["candidates"] == 0            # beyond the bf16 scan's depths: the fp32 scan
+    assert_bits(D, I, Q, X, 9000)
     D, I = ix.search(Q, 5000)
-    assert ix.last_bf16_stats()["candidates"] == 0            # the fp32 scan (deep passes)
+    assert ix.last_bf16_stats()["candidates"] == 5000         # a list is never shorter than the depth
     assert_bits(D, I, Q, X, 5000)
     D, I = ix.search(Q, 2048)
     assert ix.last_bf16_stats()["candidates"] == 4096
@@ -594,7 +626,7 @@ def test_forced_candidate_count_does_not_lift_depth_limits(R):
     ix2 = index(R, X, "bf16")
     ix2.set_param("bf16_candidates", 4096)
     with pytest.raises(IpxError) as e:
-        ix2.search(Q, 5000)
+        ix2.search(Q, 9000)
     assert e.value.code == 1
     D, I = ix2.search(Q, 1638)
     assert_bits(D, I, Q, bf16_round(X), 1638)

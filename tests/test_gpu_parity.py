@@ -170,13 +170,19 @@ def test_dimension_mismatch_and_k_errors(R):
         r.search(np.zeros((3, 8), np.float32), (1 << 20) + 1)       # IPX_MAX_DEPTH
 
 
-# ---- k beyond one pass (IPX_MAX_K = 2048): faiss takes any k (reference retriever.py:19, --depth) ----------
+# ---- k beyond one LDS sort (IPX_MAX_K = 2048): faiss takes any k (reference retriever.py:19, --depth) ------
+# up to DEEP_MAX_K = 16384 in one scan (lists left unsorted per split, deep_finish_kernel), beyond that one scan per
+# 16384 ranks under a ceiling
 @pytest.mark.parametrize("n,d,nq,k,storage", [
-    (20000, 64, 37, 5000, "f32"),          # small-batch first pass, then passes under a ceiling
+    (20000, 64, 37, 5000, "f32"),          # one query block spread over every CU
     (20000, 64, 300, 5000, "f32"),         # two query blocks
-    (20000, 64, 300, 4096, "bf16scan"),    # exactly two full passes; an index that also keeps a bf16 copy
-    (3000, 32, 70, 5000, "f32"),           # k > ntotal: two passes, then padding
-    (2049, 16, 5, 2049, "f32"),            # one rank beyond a pass
+    (20000, 64, 300, 4096, "bf16scan"),    # an index that also keeps a bf16 copy
+    (3000, 32, 70, 5000, "f32"),           # k > ntotal: padding
+    (2049, 16, 5, 2049, "f32"),            # one rank beyond a sorted list
+    (40000, 16, 70, 16384, "f32"),         # the deepest single pass: one workgroup per CU
+    (40000, 16, 9, 16385, "f32"),          # one rank beyond it: a second pass under a ceiling
+    (50000, 16, 5, 40000, "f32"),          # three passes
+    (9000, 24, 260, 9000, "f32"),          # every row, sorted
 ])
 def test_search_deeper_than_one_pass(R, n, d, nq, k, storage):
     X, Q = gaussian(77, (n, d)), gaussian(78, (nq, d))
@@ -209,6 +215,18 @@ def test_deep_search_ties_across_the_pass_boundary(R):
     rz = build(R, Z)
     Dz, Iz = rz.search(np.ones((3, 16), np.float32), 5000)
     assert (Dz == 0).all() and (Iz == np.arange(5000)).all()
+    # the same across the boundary of two scans (rank 16384 = 3 * 5461 + 1: inside a triple), and 20000 all-equal scores
+    base = gaussian(7, (7000, 16))
+    X = np.concatenate([base, base, base], axis=0)
+    Q = gaussian(8, (5, 16))
+    r = build(R, X)
+    D, I = r.search(Q, 21000)
+    assert_bit_exact(D, I, Q, X, 21000)
+    assert np.array_equal(D[:, 0::3], D[:, 1::3]) and (I[:, 0::3] < I[:, 1::3]).all() and (I[:, 1::3] < I[:, 2::3]).all()
+    Z = np.zeros((20000, 8), np.float32)
+    rz = build(R, Z)
+    Dz, Iz = rz.search(np.ones((2, 8), np.float32), 20000)
+    assert (Dz == 0).all() and (Iz == np.arange(20000)).all()
 
 
 def test_deep_search_skips_nan_rows(R):
