@@ -109,6 +109,28 @@ int scratch_ptr(int device, void** out) {
     return 0;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and device while the size does not grow (the call is
+// not free, and the small-batch paths launch several kernels per search that need it)
+int ensure_dynamic_lds(const void* kern, int bytes) {
+    struct Entry { const void* kern; int device; int bytes; };
+    static std::mutex mu;
+    static std::vector<Entry> seen;
+    if (bytes <= 64 * 1024) return 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    for (Entry& e : seen)
+        if (e.kern == kern && e.device == dev) {
+            if (e.bytes >= bytes) return 0;
+            IPX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            e.bytes = bytes;
+            return 0;
+        }
+    IPX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    seen.push_back({kern, dev, bytes});
+    return 0;
+}
+
 int next_pow2(int x) {
     int p = 1;
     while (p < x) p <<= 1;
@@ -241,13 +263,14 @@ int grow_corpus_h(ipx_index* ix, int64_t need_tiles, hipStream_t st) {
 }
 
 int launch_pack_bf16(const void* src, int dtype, int64_t n, int64_t n_pad, int d, uint16_t* dst, int64_t row0,
-                     int rows_per_tile, int nks_h, int parts, hipStream_t st, int swz = 0) {
+                     int rows_per_tile, int nks_h, int parts, hipStream_t st, int swz = 0, void* zero = nullptr,
+                     size_t zero_bytes = 0) {
     const int64_t total = n_pad * nks_h * 4;
     if (total == 0) return 0;
     const int64_t blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return fail(IPX_ERR_ARG, "pack: too many rows in one call");
     hipLaunchKernelGGL(ipx::pack_rows_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dtype, n, n_pad, d,
-                       dst, row0, rows_per_tile, nks_h, parts, swz);
+                       dst, row0, rows_per_tile, nks_h, parts, swz, (uint32_t*)zero, (int64_t)(zero_bytes / 4));
     IPX_HIP(hipGetLastError());
     return 0;
 }
@@ -425,7 +448,7 @@ int scan_f32_small_launch(ipx_index* ix, const SmallGeom& g, const SmallBufs& b,
         const int* todo = nullptr;
         if (S >= 16) {
             hipLaunchKernelGGL(ipx::merge_pool_kernel, dim3((unsigned)nq), dim3(256), 0, st, (const float*)b.partD,
-                               (const int64_t*)b.partI, S, k, k, (int64_t)k, (int64_t)S * k, dD, dI, (int*)b.flags);
+                               (const int64_t*)b.partI, S, k, k, (int64_t)k, (int64_t)S * k, dD, dI, (int*)b.flags, 0);
             IPX_HIP(hipGetLastError());
             todo = (const int*)b.flags;
         }
@@ -599,7 +622,7 @@ int scan_f32_path(ipx_index* ix, const float* dq, const float* dw, int A, int lo
             if (int rc = ix->flags.ensure((size_t)nq * sizeof(int))) return rc;
             hipLaunchKernelGGL(ipx::merge_pool_kernel, dim3((unsigned)nq), dim3(256), 0, st, (const float*)ix->partD.p,
                                (const int64_t*)ix->partI.p, S_out, k, k, (int64_t)k, (int64_t)S_out * k, dD, dI,
-                               (int*)ix->flags.p);
+                               (int*)ix->flags.p, 0);
             IPX_HIP(hipGetLastError());
             todo = (const int*)ix->flags.p;
         }
@@ -650,6 +673,19 @@ int scan_f32_deep(ipx_index* ix, const float* dq, const float* dw, int A, int lo
                            (float*)ix->ceilD.p, (int64_t*)ix->ceilI.p, (int*)nullptr);
         IPX_HIP(hipGetLastError());
     }
+    return 0;
+}
+
+// rescore_kernel over `nblocks` lists: 16 waves per list for the few lists of a small batch (latency), 4 otherwise.
+int launch_rescore(const ipx::RescoreParams& rp, int64_t nblocks, hipStream_t st) {
+    const int fixed = ((rp.nks * (rp.x_is_bf16 ? 32 : 16) * 4 + 15) & ~15) + rp.P * 8 + (rp.P <= ipx::RS_RANK_SORT ? rp.P * 8 : 0);
+    const int per_wave = ipx::RS_KB * 16 * ipx::RS_ROW;
+    const int nw = (nblocks <= 128 && fixed + 16 * per_wave <= 160 * 1024) ? 16 : 4;
+    const int rlds = fixed + nw * per_wave;
+    void (*kern)(const ipx::RescoreParams) = nw == 16 ? ipx::rescore_kernel<16> : ipx::rescore_kernel<4>;
+    if (int rc = ensure_dynamic_lds((const void*)kern, rlds)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(nw * 64), rlds, st, rp);
+    IPX_HIP(hipGetLastError());
     return 0;
 }
 
@@ -732,15 +768,16 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     const size_t ctr_bytes = ((size_t)(nqb + S) * sizeof(uint32_t) + 255) / 256 * 256;
     // published bounds: up to 4 values per split and query on the small-batch short-list path
     const size_t pub_bytes = ctr_bytes + (size_t)G * bq * (small ? 4 : 1) * sizeof(uint32_t);
-    if (int rc = ix->pub.ensure(pub_bytes)) return rc;
-    IPX_HIP(hipMemsetAsync(ix->pub.p, 0, pub_bytes, st));
+    if (int rc = ix->pub.ensure(pub_bytes)) return rc;          // (cleared by the pack kernel below)
 
     // large batches, one query part: the ping-pong kernels (both operands in LDS: any even number of K-stages;
     // corpus operand straight into registers: a multiple of 6)
     const bool pp = !small && !deep && qparts == 1 && (ix->bf16_pp == 1 || ix->bf16_pp == 2) && (nks & 1) == 0;
     const bool dx = !small && !deep && qparts == 1 && (ix->bf16_pp == 3 || ix->bf16_pp == 4) && nks % 6 == 0;
     if (timing) IPX_HIP(hipEventRecord(ix->ev[0], st));
-    if (int rc = launch_pack_bf16(qf, IPX_F32, nq, (int64_t)nqb * bq, d, (uint16_t*)ix->Qp.p, 0, bq, nks, qparts, st, dx ? 1 : 0)) return rc;
+    if (int rc = launch_pack_bf16(qf, IPX_F32, nq, (int64_t)nqb * bq, d, (uint16_t*)ix->Qp.p, 0, bq, nks, qparts, st, dx ? 1 : 0,
+                                  ix->pub.p, pub_bytes))
+        return rc;
     if (timing) IPX_HIP(hipEventRecord(ix->ev[1], st));
 
     ipx::ScanParams p;
@@ -811,12 +848,13 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
             small ? (qparts == 2 ? ipx::scan_bf16_kernel<1, 2> : ipx::scan_bf16_kernel<1, 1>)
                   : (qparts == 2 ? ipx::scan_bf16_w16_kernel<2, false, 0, false, 2> : ipx::scan_bf16_w16_kernel<1, true, 0, false, 2>);
 #endif
-        IPX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if (int rc = ensure_dynamic_lds((const void*)kern, std::max(lds, 64 * 1024 + 1))) return rc;
         hipLaunchKernelGGL(kern, dim3(G), dim3((pp || dx) ? 512 : w16 ? 1024 : ipx::HTHREADS), lds, st, p, nsortwaves);
     }
     IPX_HIP(hipGetLastError());
     if (timing) IPX_HIP(hipEventRecord(ix->ev[2], st));
 
+    const int* pool_todo = nullptr;
     if (deep) {
         if (int rc = launch_deep_finish(ix, S, kc, kc, nq, (float*)ix->candD.p, (int64_t*)ix->candI.p, st)) return rc;
     } else if (S > 1) {
@@ -827,27 +865,44 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
                                         hipFuncAttributeMaxDynamicSharedMemorySize, mlds));
         // many lists (few queries spread over every CU): cut by the union bound and sort once;
         // the fold kernel then only serves queries whose pool overflowed
-        const int* todo = nullptr;
+        // (a query whose pool overflows — more near-ties at the cut than the pool holds — is folded list by list in the
+        // same kernel: no second launch that does nothing in the common case)
         if (S >= 16) {
-            hipLaunchKernelGGL(ipx::merge_pool_kernel, dim3((unsigned)nq), dim3(256), 0, st, (const float*)ix->partD.p,
+            if (mlds + 52 * 1024 > 64 * 1024)
+                if (int rc = ensure_dynamic_lds((const void*)ipx::merge_pool_kernel, std::max(mlds, 64 * 1024 + 1))) return rc;
+            hipLaunchKernelGGL(ipx::merge_pool_kernel, dim3((unsigned)nq), dim3(256), mlds, st, (const float*)ix->partD.p,
                                (const int64_t*)ix->partI.p, S, kc, kc, (int64_t)kc, (int64_t)S * kc,
-                               (float*)ix->candD.p, (int64_t*)ix->candI.p, (int*)ix->flags.p);
+                               (float*)ix->candD.p, (int64_t*)ix->candI.p, (int*)nullptr, P);
             IPX_HIP(hipGetLastError());
-            todo = (const int*)ix->flags.p;
+        } else {
+            hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st,
+                               (const float*)ix->partD.p, (const int64_t*)ix->partI.p, S, nq, kc, kc, P, 1,
+                               (int64_t)kc, (int64_t)S * kc, (float*)ix->candD.p, (int64_t*)ix->candI.p, (const int*)nullptr,
+                               (int64_t)0);
+            IPX_HIP(hipGetLastError());
         }
-        hipLaunchKernelGGL(ipx::merge_topk_kernel, dim3((unsigned)nq), dim3(256), mlds, st,
-                           (const float*)ix->partD.p, (const int64_t*)ix->partI.p, S, nq, kc, kc, P, 1,
-                           (int64_t)kc, (int64_t)S * kc, (float*)ix->candD.p, (int64_t*)ix->candI.p, todo, (int64_t)0);
-        IPX_HIP(hipGetLastError());
     }
     if (timing) {
         IPX_HIP(hipEventRecord(ix->ev[3], st));
         ix->ev_merge = true;
     }
 
+    // the pass's flags (which queries failed the margin check; behind them the scan's error word and the outlier count)
+    // are written by the rescoring kernel straight into pinned host memory: one wait, no copy
+    if (ix->hflags_n < (size_t)nq + 2) {
+        IPX_HIP(hipStreamSynchronize(st));          // (an earlier pass's kernel may still write the old block)
+        if (ix->hflags) (void)hipHostFree(ix->hflags);
+        ix->hflags = nullptr;
+        ix->hflags_n = 0;
+        const size_t want = std::max<size_t>((size_t)nq + 2, 4096);
+        hipError_t e = hipHostMalloc((void**)&ix->hflags, want * sizeof(int), hipHostMallocDefault);
+        if (e != hipSuccess) { ix->hflags = nullptr; return fail(IPX_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+        ix->hflags_n = want;
+    }
     ipx::RescoreParams rp;
     rp.candD = (const float*)ix->candD.p;
     rp.candI = (const int64_t*)ix->candI.p;
+    rp.todo = pool_todo;
     rp.q = qf;
     rp.qmap = nullptr;
     rp.x_is_bf16 = ix->storage == 2;
@@ -856,7 +911,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     rp.maxsq = (const uint32_t*)ix->maxsq.p;
     rp.outD = dD;
     rp.outI = dI;
-    rp.flags = (int*)ix->flags.p;
+    rp.flags = ix->hflags;
     rp.err = (const int*)ix->err.p;
     rp.outl_count = ix->outl.p ? &((const ipx::OutlierState*)ix->outl.p)->count : nullptr;
     rp.shared_list = 0;
@@ -869,11 +924,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     rp.k = k;
     rp.kc = kc;
     rp.P = next_pow2(kc);
-    const int rlds = ((rp.nks * (rp.x_is_bf16 ? 32 : 16) * 4 + 15) & ~15) + rp.P * 8 + 4 * ipx::RS_KB * 16 * ipx::RS_ROW;
-    if (rlds > 64 * 1024)
-        IPX_HIP(hipFuncSetAttribute((const void*)ipx::rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rlds));
-    hipLaunchKernelGGL(ipx::rescore_kernel, dim3((unsigned)nq), dim3(256), rlds, st, rp);
-    IPX_HIP(hipGetLastError());
+    if (int rc = launch_rescore(rp, nq, st)) return rc;
     if (timing) {
         IPX_HIP(hipEventRecord(ix->ev[4], st));
         ix->ev_rescore = true;
@@ -886,19 +937,8 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
         ix->last_kc = kc;
     }
 
-    // which queries failed the margin check? (the one host round trip of a pass: the flags and, behind them, the
-    // scan's error word, which the rescoring kernel copies there — one copy into pinned memory, one wait)
-    if (ix->hflags_n < (size_t)nq + 2) {
-        if (ix->hflags) (void)hipHostFree(ix->hflags);
-        ix->hflags = nullptr;
-        ix->hflags_n = 0;
-        const size_t want = std::max<size_t>((size_t)nq + 2, 4096);
-        hipError_t e = hipHostMalloc((void**)&ix->hflags, want * sizeof(int), hipHostMallocDefault);
-        if (e != hipSuccess) { ix->hflags = nullptr; return fail(IPX_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
-        ix->hflags_n = want;
-    }
+    // which queries failed the margin check? (the one host round trip of a pass)
     const int* flags = ix->hflags;
-    IPX_HIP(hipMemcpyAsync(ix->hflags, ix->flags.p, (size_t)(nq + 2) * sizeof(int), hipMemcpyDeviceToHost, st));
     IPX_HIP(hipStreamSynchronize(st));
     ix->n_outliers = std::min(flags[nq + 1], ipx::OUTLIER_MAX);
     if (flags[nq]) {
@@ -981,16 +1021,12 @@ int exact_rows_path(ipx_index* ix, const float* qf, const std::vector<int>& sel,
     rp.k = k;
     rp.kc = kc;
     rp.P = next_pow2(kc);
-    const int rlds = ((rp.nks * (rp.x_is_bf16 ? 32 : 16) * 4 + 15) & ~15) + rp.P * 8 + 4 * ipx::RS_KB * 16 * ipx::RS_ROW;
-    if (rlds > 64 * 1024)
-        IPX_HIP(hipFuncSetAttribute((const void*)ipx::rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rlds));
     const int P = next_pow2(k), mlds = P * 24;
     if (mlds > 64 * 1024 && k <= IPX_MAX_K)
         IPX_HIP(hipFuncSetAttribute((const void*)ipx::merge_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mlds));
     for (int f : sel) {
         IPX_HIP(hipMemsetD32Async((hipDeviceptr_t)ix->sel.p, f, (size_t)nlists, st));
-        hipLaunchKernelGGL(ipx::rescore_kernel, dim3((unsigned)nlists), dim3(256), rlds, st, rp);
-        IPX_HIP(hipGetLastError());
+        if (int rc = launch_rescore(rp, nlists, st)) return rc;
         // the lists' top-k (sorted) -> row f of the result
         if (k > IPX_MAX_K) {
             if (int rc = merge_deep((const float*)ix->partD.p, (const int64_t*)ix->partI.p, (int)nlists, 1, k, k,
@@ -1043,11 +1079,7 @@ int merge_outlier_rows(ipx_index* ix, const float* qf, int64_t nq, int k, float*
     rp.k = k;
     rp.kc = ipx::OUTLIER_MAX;
     rp.P = ipx::OUTLIER_MAX;
-    const int rlds = ((rp.nks * 16 * 4 + 15) & ~15) + rp.P * 8 + 4 * ipx::RS_KB * 16 * ipx::RS_ROW;
-    if (rlds > 64 * 1024)
-        IPX_HIP(hipFuncSetAttribute((const void*)ipx::rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rlds));
-    hipLaunchKernelGGL(ipx::rescore_kernel, dim3((unsigned)nq), dim3(256), rlds, st, rp);
-    IPX_HIP(hipGetLastError());
+    if (int rc = launch_rescore(rp, nq, st)) return rc;
     if (k > IPX_MAX_K)       // lists beyond one LDS sort: the two blocks [2][nq][k] through the deep merge
         return merge_deep((const float*)ix->sideD.p, (const int64_t*)ix->sideI.p, 2, nq, k, k, dD, dI, st);
     const int P = next_pow2(k), mlds = P * 24;

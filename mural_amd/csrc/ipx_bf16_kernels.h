@@ -107,9 +107,13 @@ __device__ __forceinline__ int dx_sigma(int q) { return (((q ^ (q >> 1)) & 1) <<
 // swz == 1 (queries only): the dx_sigma swizzle instead of the corpus one.
 __global__ void __launch_bounds__(256)
 pack_rows_bf16_kernel(const void* __restrict__ src, int dtype, int64_t n, int64_t n_pad, int d,
-                      uint16_t* __restrict__ dst, int64_t row0, int rows_per_tile, int nks, int parts, int swz) {
+                      uint16_t* __restrict__ dst, int64_t row0, int rows_per_tile, int nks, int parts, int swz,
+                      uint32_t* __restrict__ zero, int64_t zero_words) {
     const int nchunks = nks * 4;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // (queries only) the scan's per-search counters and published bounds start at zero: cleared here, by the kernel
+    // that runs right before the scan anyway, instead of by a fill of its own
+    for (int64_t i = gid; i < zero_words; i += (int64_t)gridDim.x * 256) zero[i] = 0u;
     const int64_t r = gid / nchunks;
     const int c = (int)(gid - r * nchunks);
     if (r >= n_pad) return;
@@ -445,8 +449,9 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
     const int fill_limit = p.cap - 2 * HBD;
     // Small batches with short lists (candidates <= 4 S): no compaction episodes unless a queue fills.
     // Each split deals its tiles round-robin to r = ceil(candidates / S) sub-splits and keeps the best
-    // score of each by an LDS max beside the appends; the S r bests are published / polled at r, 2r,
-    // 4r, ... tiles and every 64, and their minimum bounds the list's last score from below (S r
+    // score of each by an LDS max beside the appends; the S r bests are published / polled at r, 4r,
+    // 16r, 64r ... tiles (round 3: half the polls of the power-of-two schedule, ~1 % less scan time at 1-16 queries, the
+    // same at 64 — scripts/small_ab.py), and their minimum bounds the list's last score from below (S r
     // disjoint sets of rows, each holding a row at or above it). With r == 1: every split publishes
     // its best. (Each split sees only N / S rows, so its own k-th best is a poor threshold anyway;
     // the union bound is the one that prunes.)
@@ -651,7 +656,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
         if (p.trace) { tr_e1 = __builtin_readcyclecounter(); tr_epi += tr_e1 - tr_e0; }
         if constexpr (QW == 1) {
             const int rounds = tiles_done / rs;                    // completed rounds over the sub-splits
-            if (fast1 && tiles_done == rounds * rs && ((rounds & (rounds - 1)) == 0 || (tiles_done & 63) == 0)) {
+            if (fast1 && tiles_done == rounds * rs && is_pow4(rounds)) {
                 // publish the sub-splits' bests, take a bound from every split's values as the new floor.
                 // After the first round every split is at the same point: wait (bounded) until all of
                 // them have published, so the next tile already runs against a bound.
@@ -799,6 +804,7 @@ struct RescoreParams {
     int* flags;              // [nq] (+ 1 when err is given)
     const int* err;          // optional: the scan's error word, copied to flags[nq] so that one readback brings both
     const int* outl_count;   // optional (with err): the index's outlier-row count, copied to flags[nq + 1]
+    const int* todo = nullptr;   // optional [nq]: 1 = merge_pool_kernel left this query without a list (pool overflow)
     int nq;                  // queries of the pass (position of that copy)
     int64_t id_base;
     float acc_coef;          // accumulation-error coefficient (host: margin_acc_coef)
@@ -812,20 +818,26 @@ __device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w 
 
 constexpr int RS_KB = 4;        // K-stages fetched per round
 constexpr int RS_ROW = 80;      // LDS bytes per staged 64-byte line (80: 16 lines, 16 different bank groups)
+constexpr int RS_RANK_SORT = 1024;   // lists of up to this many scored candidates are sorted by rank, not bitonic
 
-__global__ void __launch_bounds__(256)
+// NW waves per query: 4 for large batches (the chip is full of workgroups anyway), 16 for small ones, where a query's
+// workgroup is alone on its CU and the time is the latency of its dependent rounds — 256 candidates in flight per
+// round instead of 64. The rows' K-stages are fetched one group ahead of the fmaf chains that consume them.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
 rescore_kernel(const RescoreParams p) {
+    constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int dpad = p.nks * (p.x_is_bf16 ? 32 : 16);
     float* qs = (float*)smem;                                  // [dpad]
     uint64_t* keys = (uint64_t*)(smem + (size_t)((dpad * 4 + 15) & ~15));   // [P]
-    __shared__ float red[8];
+    __shared__ float red[2 * NW];
     __shared__ int s_m, s_post;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t qi = blockIdx.x;
     const float* q = p.q + (p.qmap ? (int64_t)p.qmap[qi] : qi) * (int64_t)p.d;
     float ss = 0.f, dd = 0.f;
-    for (int e = tid; e < dpad; e += 256) {
+    for (int e = tid; e < dpad; e += NT) {
         const float v = e < p.d ? q[e] : 0.f;
         qs[e] = v;
         ss = fmaf(v, v, ss);
@@ -836,10 +848,12 @@ rescore_kernel(const RescoreParams p) {
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off); dd += __shfl_xor(dd, off); }
-    if (lane == 0) { red[wave] = ss; red[4 + wave] = dd; }
+    if (lane == 0) { red[wave] = ss; red[NW + wave] = dd; }
     __syncthreads();
-    const float qn = sqrtf(red[0] + red[1] + red[2] + red[3]);
-    const float dqn = sqrtf(red[4] + red[5] + red[6] + red[7]);
+    float qn2 = 0.f, dqn2 = 0.f;
+    for (int w = 0; w < NW; ++w) { qn2 += red[w]; dqn2 += red[NW + w]; }
+    const float qn = sqrtf(qn2);
+    const float dqn = sqrtf(dqn2);
     const float Mx = sqrtf(__uint_as_float(p.maxsq[0])), Dx = sqrtf(__uint_as_float(p.maxsq[1]));
     const float eps = 1.002f * ((qn + dqn) * Dx + dqn * Mx) + p.acc_coef * (qn + dqn) * (Mx + Dx);
     // Every partial sum of either chain is bounded by (|q| + |dq|)(Mx + Dx). Only while that stays well inside the
@@ -854,12 +868,35 @@ rescore_kernel(const RescoreParams p) {
 
     const float* cD = p.candD + (p.shared_list ? 0 : qi * (int64_t)p.kc);
     const int64_t* cI = p.candI + (p.shared_list ? 0 : qi * (int64_t)p.kc);
+    // The list is sorted: valid entries first, scores descending. Its length and the margin cut are counted by all
+    // threads at once (one round of loads each) instead of searched by one thread (a dozen dependent loads).
+    __shared__ int s_nvalid, s_nge;
+    const bool have_list = !(p.todo && p.todo[qi]);
+    if (tid == 0) { s_nvalid = 0; s_nge = 0; }
+    __syncthreads();
+    // a-priori margin test of a full list: the entries at or above thr = a_k - 2 eps (kc >= k; a list that is not
+    // full, or shared, never uses the count: its first entries may be padding, cD may be null)
+    const float thr = (have_list && !p.shared_list) ? cD[p.k - 1] - 2.f * eps : 0.f;
+    if (have_list) {
+        int nv = 0, ng = 0;
+        for (int i = tid; i < p.kc; i += NT) {
+            nv += cI[i] >= 0 ? 1 : 0;
+            if (!p.shared_list) ng += cD[i] >= thr ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { nv += __shfl_xor(nv, off); ng += __shfl_xor(ng, off); }
+        if (lane == 0) { if (nv) atomicAdd(&s_nvalid, nv); if (ng) atomicAdd(&s_nge, ng); }
+    }
+    __syncthreads();
     if (tid == 0) {
-        // candidates are sorted: valid ones first. binary search the count, then the margin cut.
-        int lo = 0, hi = p.kc;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cI[mid] >= 0) lo = mid + 1; else hi = mid; }
-        const int nvalid = lo;
-        int m = nvalid, flag = 0, post = 0;
+        int m = 0, flag = 0, post = 0;
+        if (!have_list) {
+            // merge_pool_kernel could not build this query's list (more than its pool of near-ties at the cut):
+            // there is no list to rescore; the query is repeated like one whose list failed the margin test
+            flag = 1;
+        } else {
+        const int nvalid = s_nvalid;
+        m = nvalid;
         if (p.shared_list) {
             // the outlier rows: every listed row is scored, nothing was cut off
         } else if (!tame) {
@@ -869,15 +906,13 @@ rescore_kernel(const RescoreParams p) {
             // result order (score desc, id asc) already — its first k entries are the answer, whatever ties follow
             m = nvalid < p.k ? nvalid : p.k;
         } else if (nvalid >= p.kc) {                // the list is full: it may have cut rows off
-            const float thr = cD[p.k - 1] - 2.f * eps;   // kc >= k
-            if (cD[p.kc - 1] < thr) {
-                lo = p.k; hi = p.kc;                // first index with score < thr
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (cD[mid] >= thr) lo = mid + 1; else hi = mid; }
-                m = lo;
+            if (s_nge < p.kc && s_nge >= p.k) {     // its last score lies below thr: everything from there on is cut
+                m = s_nge;                          // (the k-th score itself is >= thr; a NaN thr counts nothing: flagged)
             } else {
-                flag = 1;                           // includes eps = NaN / inf
+                flag = 1;
                 post = p.post && eps < INFINITY;    // every candidate is scored; decided behind the sort
             }
+        }
         }
         s_m = m;
         s_post = post;
@@ -894,12 +929,15 @@ rescore_kernel(const RescoreParams p) {
     // so a wave instruction brings 16 whole lines — one request per line instead of four partial
     // ones — for RS_KB K-stages in a row; the lines go through LDS to lane r < 16, which owns
     // candidate r and runs the ordered fmaf chain (the order of the fp32 scan's MFMA).
-    for (int i = tid; i < p.P; i += 256) keys[i] = 0;
+    for (int i = tid; i < p.P; i += NT) keys[i] = 0;
     __syncthreads();            // a wave writes keys that other waves' threads cleared
-    char* stage = (char*)(keys + p.P) + wave * (RS_KB * 16 * RS_ROW);
+    // short lists are sorted by rank (one pass, no barriers inside) into a second array behind the first
+    const bool by_rank = p.P <= RS_RANK_SORT;
+    uint64_t* sorted = keys + p.P;                            // [P] when by_rank
+    char* stage = (char*)(sorted + (by_rank ? p.P : 0)) + wave * (RS_KB * 16 * RS_ROW);
     const int R = p.x_is_bf16 ? HBD : BD;                 // rows per tile of the packed layout
     const size_t ks_stride = (size_t)R * 64;              // bytes between a row's consecutive K-stages
-    for (int g0 = wave * 16; g0 < m; g0 += 64) {
+    for (int g0 = wave * 16; g0 < m; g0 += NW * 16) {
         const int r = lane >> 2, pc = lane & 3;
         const int ci = g0 + r < m ? g0 + r : m - 1;
         const int64_t row = cI[ci] - p.id_base;
@@ -911,15 +949,19 @@ rescore_kernel(const RescoreParams p) {
         const int64_t myrow = lane < 16 ? cI[my] - p.id_base : 0;
         const int mysw = (int)(((myrow % R) >> 2) & 3);
         float acc = 0.f;
-        for (int ks0 = 0; ks0 < p.nks; ks0 += RS_KB) {
-            uint4 v[RS_KB];
+        uint4 v[RS_KB];
 #pragma unroll
-            for (int u = 0; u < RS_KB; ++u) {
-                const int ks = ks0 + u < p.nks ? ks0 + u : p.nks - 1;
-                v[u] = *(const uint4*)(src + (size_t)ks * ks_stride);
-            }
+        for (int u = 0; u < RS_KB; ++u) v[u] = *(const uint4*)(src + (size_t)(u < p.nks ? u : p.nks - 1) * ks_stride);
+        for (int ks0 = 0; ks0 < p.nks; ks0 += RS_KB) {
 #pragma unroll
             for (int u = 0; u < RS_KB; ++u) *(uint4*)(stage + (u * 16 + r) * RS_ROW + pc * 16) = v[u];
+            if (ks0 + RS_KB < p.nks) {                     // the next group is on its way while this one is multiplied
+#pragma unroll
+                for (int u = 0; u < RS_KB; ++u) {
+                    const int ks = ks0 + RS_KB + u < p.nks ? ks0 + RS_KB + u : p.nks - 1;
+                    v[u] = *(const uint4*)(src + (size_t)ks * ks_stride);
+                }
+            }
             wave_lds_sync();
             if (lane < 16) {
                 const int nb = p.nks - ks0 < RS_KB ? p.nks - ks0 : RS_KB;
@@ -953,23 +995,41 @@ rescore_kernel(const RescoreParams p) {
             keys[g0 + lane] = make_key(acc, (uint32_t)myrow);
     }
     __syncthreads();
-    for (int size = 2; size <= p.P; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < (p.P >> 1); i += 256) {
-                const int lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1));
-                const int hi = lo + stride;
-                const bool desc = (lo & size) == 0;
-                const uint64_t x = keys[lo], y = keys[hi];
-                if ((x < y) == desc) { keys[lo] = y; keys[hi] = x; }
+    const uint64_t* res = keys;
+    if (by_rank) {
+        // rank of a key = how many keys are larger (distinct rows: distinct keys; the zeros of rows that were not
+        // admitted all rank behind every real key and are never read)
+        for (int i = tid; i < m; i += NT) {
+            const uint64_t key = keys[i];
+            if (key) {
+                int rank = 0;
+                for (int j = 0; j < m; ++j) rank += keys[j] > key ? 1 : 0;
+                sorted[rank] = key;
             }
-            __syncthreads();
         }
+        for (int i = tid; i < m; i += NT) if (!keys[i]) atomicAdd(&s_m, -1);     // s_m: the number of real keys
+        __syncthreads();
+        res = sorted;
+    } else {
+        for (int size = 2; size <= p.P; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = tid; i < (p.P >> 1); i += NT) {
+                    const int lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool desc = (lo & size) == 0;
+                    const uint64_t x = keys[lo], y = keys[hi];
+                    if ((x < y) == desc) { keys[lo] = y; keys[hi] = x; }
+                }
+                __syncthreads();
+            }
+    }
+    const int nres = by_rank ? s_m : p.P;                      // entries of res that hold a key (rank sort) / slots (sort)
     if (s_post && tid == 0) {
-        const uint64_t key = keys[p.k - 1];                    // k <= kc <= P
+        const uint64_t key = p.k - 1 < nres ? res[p.k - 1] : 0;        // k <= kc <= P
         if (key && cD[p.kc - 1] + eps < f32_unordered((uint32_t)(key >> 32))) p.flags[qi] = 0;
     }
-    for (int i = tid; i < p.k; i += 256) {
-        const uint64_t key = i < p.P ? keys[i] : 0;
+    for (int i = tid; i < p.k; i += NT) {
+        const uint64_t key = i < nres ? res[i] : 0;
         p.outD[qi * p.k + i] = key ? f32_unordered((uint32_t)(key >> 32)) : -FLT_MAX;
         p.outI[qi * p.k + i] = key ? p.id_base + (int64_t)(uint32_t)(~(uint32_t)key) : -1;
     }

@@ -263,7 +263,7 @@ scan_f32_small_kernel(const ScanParams p, const int nsortwaves) {
             }
         }
         const int rounds = tiles_done / rs;                        // completed rounds over the sub-splits
-        if (fast1 && tiles_done == rounds * rs && ((rounds & (rounds - 1)) == 0 || (tiles_done & 31) == 0)) {
+        if (fast1 && tiles_done == rounds * rs && is_pow4(rounds)) {
             // publish the sub-splits' bests, take the minimum over all splits as the new floor. After
             // the first round every split is at the same point: wait (bounded) until all of them
             // have published, so the next step already runs against a bound.

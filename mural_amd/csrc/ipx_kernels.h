@@ -101,7 +101,6 @@ __device__ __forceinline__ float f32_below(float x) {
 }
 
 __device__ __forceinline__ bool is_pow4(int n) { return n > 0 && (n & (n - 1)) == 0 && (n & 0x55555555); }
-
 // Workgroup id -> logical id (which query block / split it is). For speed only; any bijection
 // is correct. Observed dispatch: blocks b and b+8 share an XCD (and its L2); on an XCD the
 // first 32 blocks get a CU each and the next 32 become the second workgroup of those CUs, where
@@ -979,22 +978,16 @@ __device__ __forceinline__ void wg_cmpx(uint32_t* os, int64_t* id, int lo, int h
     if (entry_before(b, ib, a, ia) == desc) { os[lo] = b; id[lo] = ib; os[hi] = a; id[hi] = ia; }
 }
 
-__global__ void __launch_bounds__(256)
-merge_topk_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, int S, int64_t nq,
-                  int k_in, int k_out, int P, int lists_sorted, int64_t shard_stride, int64_t query_stride,
-                  float* __restrict__ outD, int64_t* __restrict__ outI, const int* __restrict__ only_flagged,
-                  int64_t shard_stride_I) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (only_flagged && !only_flagged[blockIdx.x]) return;   // merge_pool_kernel already served this query
-    // lists of one shard packed into one buffer (ipx_merge_topk_packed): ids and scores a different number of
-    // elements apart from shard to shard; 0 = the same stride as the scores
-    if (shard_stride_I == 0) shard_stride_I = shard_stride;
+// The fold of query q's S lists into its top k_out, by one workgroup of 256 with 24 * P bytes of LDS at `smem`.
+__device__ __forceinline__ void fold_lists(char* smem, const float* __restrict__ D, const int64_t* __restrict__ I, int S,
+                                           int k_in, int k_out, int P, int lists_sorted, int64_t shard_stride,
+                                           int64_t query_stride, float* __restrict__ outD, int64_t* __restrict__ outI,
+                                           int64_t shard_stride_I, int64_t q) {
     int64_t* rid = (int64_t*)smem;          // [P]
     int64_t* lid = rid + P;                 // [P]
     uint32_t* ros = (uint32_t*)(lid + P);   // [P]
     uint32_t* los = ros + P;                // [P]
     const int tid = threadIdx.x;
-    const int64_t q = blockIdx.x;
 
     // os == 0 marks an empty slot (every real score orders above 0)
     for (int i = tid; i < P; i += 256) { ros[i] = 0; rid[i] = INT64_MAX; }
@@ -1046,6 +1039,19 @@ merge_topk_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, in
     }
 }
 
+__global__ void __launch_bounds__(256)
+merge_topk_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, int S, int64_t nq,
+                  int k_in, int k_out, int P, int lists_sorted, int64_t shard_stride, int64_t query_stride,
+                  float* __restrict__ outD, int64_t* __restrict__ outI, const int* __restrict__ only_flagged,
+                  int64_t shard_stride_I) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (only_flagged && !only_flagged[blockIdx.x]) return;   // merge_pool_kernel already served this query
+    // lists of one shard packed into one buffer (ipx_merge_topk_packed): ids and scores a different number of
+    // elements apart from shard to shard; 0 = the same stride as the scores
+    if (shard_stride_I == 0) shard_stride_I = shard_stride;
+    fold_lists(smem, D, I, S, k_in, k_out, P, lists_sorted, shard_stride, query_stride, outD, outI, shard_stride_I, blockIdx.x);
+}
+
 // Merge of S SORTED lists per query, S large (the scan's per-split lists when few queries spread
 // over every CU: S = 256 or 512 lists for a batch of <= 64 queries). Folding them one by one costs
 // S dependent merge rounds; this kernel cuts first. Take the first m entries of every list
@@ -1061,19 +1067,21 @@ constexpr int MERGE_POOL = 4096;
 __global__ void __launch_bounds__(256)
 merge_pool_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, int S, int k_in, int k_out,
                   int64_t shard_stride, int64_t query_stride, float* __restrict__ outD, int64_t* __restrict__ outI,
-                  int* __restrict__ todo) {
+                  int* __restrict__ todo, int fold_P) {
+    extern __shared__ __attribute__((aligned(16))) char fold_smem[];      // 24 * fold_P bytes (0: overflow -> todo)
     __shared__ int64_t pid[MERGE_POOL];
     __shared__ uint32_t pos_[MERGE_POOL];
     __shared__ uint32_t s_v;
-    __shared__ int s_n;
-    __shared__ int s_cnt[3];
-    const int tid = threadIdx.x;
+    __shared__ int s_n, s_need;
+    __shared__ int hist[256];
+    __shared__ int wtot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q = blockIdx.x;
     const int r = (k_out + S - 1) / S;
     int m = MERGE_POOL / S;
     m = m < r ? r : m;
     m = m > k_in ? k_in : m;
-    if (tid == 0) { s_v = 0; s_n = 0; s_cnt[0] = s_cnt[1] = s_cnt[2] = 0; }
+    if (tid == 0) { s_v = 0; s_n = 0; s_need = k_out; }
     if ((int64_t)S * m <= MERGE_POOL && r <= k_in) {
         // the sample: first m entries of each list, as ordered bits (0 = empty slot), in pos_
         const int nv = S * m;
@@ -1082,23 +1090,36 @@ merge_pool_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, in
             const float sc = D[s * shard_stride + q * query_stride + i];
             pos_[e] = sc > -FLT_MAX ? f32_ordered(sc) : 0u;
         }
-        __syncthreads();
-        // v = the k_out-th largest sample value, bit by bit from the top (0 if there are fewer)
-        // (three counters in rotation: one barrier per round — the counter of the round after
-        // next is cleared while this round's is read)
-        uint32_t v = 0;
-        for (int b = 31, rr = 0; b >= 0; --b, rr = rr == 2 ? 0 : rr + 1) {
-            const uint32_t cand = v | (1u << b);
-            int c = 0;
-            for (int e = tid; e < nv; e += 256) c += pos_[e] >= cand ? 1 : 0;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-            if ((tid & 63) == 0 && c) atomicAdd(&s_cnt[rr], c);
-            if (tid == 0) s_cnt[rr == 2 ? 0 : rr + 1] = 0;
+        // v = the k_out-th largest sample value (0 if fewer than k_out are real: nv >= k_out, empty slots are 0), by
+        // radix selection, 8 bits per pass: a histogram of the digit among the values that share the prefix found so
+        // far (one bin per thread), suffix sums over the bins (wave scans + the waves' totals), the bin where the
+        // count from the top reaches what is still needed
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hist[tid] = 0;
+            __syncthreads();                                   // (also: the sample / the previous pass's s_v, s_need)
+            const uint32_t v = s_v, himask = shift == 24 ? 0u : 0xffffffffu << (shift + 8);
+            for (int e = tid; e < nv; e += 256) {
+                const uint32_t x = pos_[e];
+                if ((x & himask) == v) atomicAdd(&hist[(x >> shift) & 255], 1);
+            }
             __syncthreads();
-            if (s_cnt[rr] >= k_out) v = cand;
+            const int c = hist[tid];
+            int suf = c;                                       // inclusive suffix sum inside the wave: bins >= mine
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_down(suf, off);
+                if (lane + off < 64) suf += o;
+            }
+            if (lane == 0) wtot[wave] = suf;
+            __syncthreads();
+            for (int w = wave + 1; w < 4; ++w) suf += wtot[w];
+            const int need = s_need;
+            __syncthreads();                                   // every thread has read s_need before one rewrites it
+            if (suf >= need && suf - c < need) {               // exactly one bin
+                s_v = v | ((uint32_t)tid << shift);
+                s_need = need - (suf - c);
+            }
         }
-        if (tid == 0) s_v = v;
         __syncthreads();
     }
     __syncthreads();
@@ -1118,10 +1139,37 @@ merge_pool_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, in
     __syncthreads();
     const int n = s_n;
     if (n > MERGE_POOL) {
-        if (tid == 0) todo[q] = 1;
+        // more entries at the cut than the pool holds (masses of ties: duplicate rows, a zero query): the lists are
+        // folded one by one instead — here, when the launch brought the LDS for it, else by merge_topk_kernel (todo)
+        if (fold_P > 0) {
+            __syncthreads();
+            fold_lists(fold_smem, D, I, S, k_in, k_out, fold_P, 1, shard_stride, query_stride, outD, outI, shard_stride, q);
+            if (tid == 0 && todo) todo[q] = 0;
+        } else if (tid == 0) {
+            todo[q] = 1;
+        }
         return;
     }
-    if (tid == 0) todo[q] = 0;
+    if (tid == 0 && todo) todo[q] = 0;
+    if (n <= 512) {
+        // a short pool is ordered by rank: an entry's place is the number of entries before it (distinct rows of one
+        // index: no two entries are equal) — one pass, no barriers
+        for (int i = tid; i < n; i += 256) {
+            const uint32_t o = pos_[i];
+            const int64_t id = pid[i];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += entry_before(pos_[j], pid[j], o, id) ? 1 : 0;
+            if (rank < k_out) {
+                outD[q * k_out + rank] = f32_unordered(o);
+                outI[q * k_out + rank] = id;
+            }
+        }
+        for (int i = n + tid; i < k_out; i += 256) {
+            outD[q * k_out + i] = -FLT_MAX;
+            outI[q * k_out + i] = -1;
+        }
+        return;
+    }
     int P = 2;
     while (P < n) P <<= 1;
     for (int i = n + tid; i < P; i += 256) { pos_[i] = 0; pid[i] = INT64_MAX; }
@@ -1140,7 +1188,6 @@ merge_pool_kernel(const float* __restrict__ D, const int64_t* __restrict__ I, in
         outI[q * k_out + i] = empty ? -1 : pid[i];
     }
 }
-
 
 // ---- deep lists: the splits' unsorted best-k lists of one query -> its sorted top k_out ----------------------
 // One workgroup of 1024 per query. keys: [nq][S][k_list] (each split's list in any order, counts[q * S + s] entries,
