@@ -53,12 +53,18 @@ enum ipx_status {
 
 enum ipx_dtype { IPX_F32 = 0, IPX_F16 = 1, IPX_BF16 = 2 };
 
-/* Depth of ONE pass over the corpus (the longest list the scan and merge kernels hold per query), and the
- * depth a search / merge CALL accepts: faiss.IndexFlatIP.search takes any k (retriever.py:19, --depth of
- * __main__.py:58). A call with k > IPX_MAX_K runs ceil(min(k, ntotal) / IPX_MAX_K) fp32 passes, each admitting
- * only hits after the previous pass's last one in the result order, and returns bit for bit the one sorted list
- * (the index must keep fp32 rows: storage 0 or 1; bf16-only storage serves k <= IPX_MAX_K * 4 / 5);
- * ipx_merge_topk does the same over its input lists. ipx_search_noalloc stays single-pass. */
+/* Depths. faiss.IndexFlatIP.search takes any k (retriever.py:19, --depth of __main__.py:58), and so do ipx_search /
+ * ipx_search_aspect / ipx_search_pooled / ipx_merge_topk, up to IPX_MAX_DEPTH:
+ *   k <= IPX_MAX_K     : a query's list is sorted in LDS by the scan itself (the fast path of every kernel; the limit of
+ *                        ipx_search_noalloc and ipx_merge_topk_packed).
+ *   k <= 16384         : still ONE scan of the corpus — every corpus split keeps its best k keys unsorted in HBM and a
+ *                        finishing kernel selects and sorts across the splits (8.8M x 768, 6980 queries: k = 5000 costs
+ *                        1.14 x the k = 1000 search). The bf16 scan serves k <= 8192 this way (candidate lists of up to
+ *                        16384 entries); an index that keeps only bf16 rows (storage 2) therefore serves k <= 8192
+ *                        (k <= 1638 when rows are longer than 2048 elements).
+ *   beyond             : one fp32 scan per 16384 ranks, each admitting only hits after the previous scan's last one in
+ *                        the result order; the concatenation is bit for bit the one sorted list (needs fp32 rows:
+ *                        storage 0 or 1). ipx_merge_topk does the same over its input lists, 2048 ranks per pass. */
 #define IPX_MAX_K 2048
 #define IPX_MAX_DEPTH (1 << 20)
 
@@ -106,8 +112,11 @@ int ipx_search(ipx_index* idx, const float* q, int64_t nq, int k,
 /* No counterpart in the reference: ipx_search for callers that cannot allocate device memory while they run (code
  * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc). Same results as ipx_search, bit
  * for bit. Device pointers only (q, out_D, out_I on the index's GPU), stream-ordered, returns without
- * synchronising (ipx_check reports a flagged invariant violation); the index must keep fp32 rows (storage 0 or 1).
- * Calls no hipMalloc / hipFree and creates no events: every intermediate buffer lives in a static device array of
+ * synchronising (ipx_check(idx) reports an invariant violation flagged by THIS index's searches: the error word is
+ * per index, allocated by ipx_create); the index must keep fp32 rows (storage 0 or 1: an index with a bf16 copy is
+ * scanned on its fp32 rows here). Calls no hipMalloc / hipFree, creates no events and sets no function attributes
+ * (ipx_create resolves the workspace address and the kernels' launch attributes once per device): every intermediate
+ * buffer lives in a static device array of
  * IPX_NOALLOC_SCRATCH_BYTES that each GPU the library runs on holds until the process ends. Limits: nq <=
  * IPX_NOALLOC_MAX_QUERIES, k <= IPX_MAX_K, and (nq, k, d) whose buffers fit the array with at least one corpus
  * split (the corpus is cut into as many splits as fit: fewer than ipx_search uses, so it is slower on large
@@ -173,7 +182,7 @@ int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k
  *                    candidate list cannot be proven sufficient are repeated on the fp32 scan).
  *                  2 bf16 rows only (rows given as bf16 are kept exactly, fp32 / f16 rows are
  *                    rounded to nearest even): bf16 scan, then exact fp32 scores of
- *                    <fp32 query, stored bf16 row>; half the HBM of storage 0; k <= 1638.
+ *                    <fp32 query, stored bf16 row>; half the HBM of storage 0; k <= 8192.
  *                  Queries whose candidate list cannot be proven sufficient (more near-ties than the longest
  *                  list holds: thousands of duplicate rows, a degenerate embedding) are repeated — storage 1: on
  *                  the fp32 scan; storage 2: by an exact pass over every stored row, slow but never an error.
@@ -182,7 +191,14 @@ int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k
  *                  NaN / inf rows too; at most 256 of them, more count as ordinary rows) out of the bf16 scan: every
  *                  search scores them exactly on the side and merges them in, so they do not widen the other rows'
  *                  margin. Same results, bit for bit.
- *   "bf16_candidates" : candidates per query the bf16 scan keeps (0 = automatic).
+ *                  A candidate list is only ever trusted while the norm bound of the margin rule is finite: rows with
+ *                  inf / NaN elements (or norms that overflow fp32) outside the side list — storage 2 has none, storage 1
+ *                  keeps 256 — send every query to the exact path (the bf16 score of such a row can be NaN where the
+ *                  exact one is +inf). Rows whose norms spread smoothly (no clear outliers) widen the margins instead:
+ *                  the index then learns a longer automatic list from its repeat passes (x1.25 per large batch that
+ *                  repeated more than 1 % of its queries; forgotten when rows are added or a parameter is set).
+ *   "bf16_candidates" : candidates per query the bf16 scan keeps (0 = automatic; at most 16384; never shorter than k,
+ *                  and never a way around the depth limits above).
  *   "margin_post": 1 (default) = a candidate list that fails the a-priori sufficiency test (it reaches 2e below
  *                  the k-th approximate score) is still accepted when, after exact rescoring, its last approximate
  *                  score + e lies below the k-th best exact score of its candidates — equally provable, about half
@@ -195,16 +211,11 @@ int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k
  *   "small_f32_limit" : fp32 scans of up to this many queries use the 32/64-query tile that
  *                  streams the corpus at the HBM rate (default 192; results do not depend on it).
  *   "no_small_batch" : 1 = always use the 256-query tiles (A/B measurements, tests).
- *   "bf16_waves" : large-batch bf16 scan with 8 or 16 waves per workgroup (0 = automatic: 16; results do not
- *                  depend on it).
- *   "bf16_shape16" : the 16-wave bf16 scan uses v_mfma_f32_16x16x32_bf16 (1, default: measured 2-4 % faster
- *                  on the 8.8M x 768 workload) or v_mfma_f32_32x32x16_bf16 (0).
- *   "bf16_ring"  : LDS stage-ring depth of the 16-wave bf16 scan: 2 (default: one stage in flight — measured 10 %
- *                  faster than 4 on the 8.8M x 768 workload, half the L2 fetch traffic), 3 or 4.
- *   "bf16_occ"   : with the 2-deep ring, workgroups per CU of that kernel (1 default; 2 measured slower).
- *   "bf16_variant", "bf16_map", "bf16_pp" : measurement aids of the large-batch bf16 scan (issue order behind the
- *                  stage barrier + non-temporal corpus pieces; query blocks per group of the workgroup -> (query block, split) mapping;
- *                  1 / 2 = ping-pong kernel, 3 / 4 = direct-corpus-operand kernel, see csrc/ipx_bf16_*_kernels.h).
+ *   "bf16_waves", "bf16_shape16", "bf16_ring", "bf16_occ", "bf16_variant", "bf16_map", "bf16_pp" : kernels and kernel
+ *                  variants of the large-batch bf16 scan that only a diagnostic build carries (libipx_diag.so: the same
+ *                  sources with -DIPX_DIAG, __graft_entry__.build_diag(); see csrc/ipx_bf16_*_kernels.h). The shipped
+ *                  library has one large-batch bf16 kernel (16 waves, 2-deep ring; 16x16x32 MFMA with one query part,
+ *                  32x32x16 with hi + lo parts) and accepts only these knobs' default values.
  *   "run_tiles"  : fp32 large-tile scan: corpus tiles per run of the dynamic split (0 = automatic).
  *   "trace"      : 1 = every scan workgroup records {start, end (100 MHz ticks), HW_ID,
  *                  compactions}; read back with ipx_read_trace (profiling aid). */
