@@ -196,7 +196,7 @@ int ipx_merge_topk_packed(const void* packed, int S, int64_t nq, int k_in, int k
  *                  keeps 256 — send every query to the exact path (the bf16 score of such a row can be NaN where the
  *                  exact one is +inf). Rows whose norms spread smoothly (no clear outliers) widen the margins instead:
  *                  the index then learns a longer automatic list from its repeat passes (x1.25 per large batch that
- *                  repeated more than 1 % of its queries; forgotten when rows are added or a parameter is set).
+ *                  repeated more than 0.1 % of its queries; forgotten when rows are added or a parameter is set).
  *   "bf16_candidates" : candidates per query the bf16 scan keeps (0 = automatic; at most 16384; never shorter than k,
  *                  and never a way around the depth limits above).
  *   "margin_post": 1 (default) = a candidate list that fails the a-priori sufficiency test (it reaches 2e below

@@ -167,7 +167,7 @@ struct ipx_index {
     int bf16_fail_k = INT32_MAX;
     // What this index's data has taught the automatic list length (rows whose norms spread widen every margin: MURAL
     // representations are unnormalised): the automatic candidate count is multiplied by kc_boost / 8 after a large batch
-    // that sent more than 1 % of its queries to the repeat pass, and once the longest list is reached large batches
+    // that sent more than 0.1 % of its queries to the repeat pass, and once the longest list is reached large batches
     // start with hi + lo query parts. Forgotten when rows are added or a parameter changes.
     int kc_boost = 8;
     bool parts_boost = false;
@@ -1168,8 +1168,10 @@ int scan_bf16_path(ipx_index* ix, const float* dq, const float* dw, int A, int l
     if (int rc = bf16_pass(ix, qf, nq, k, kc, qparts, dD, dI, st, true, flagged, hard)) return rc;
     const int64_t nfail = (int64_t)(flagged.size() + hard.size());
     ix->last_fallback = nfail;
-    // more than 1 % of a large batch needs a longer list: the next searches of this index start with one
-    if (ix->force_kc == 0 && nq >= 64 && (int64_t)flagged.size() * 100 > nq) {
+    // more than 0.1 % of a large batch needs a longer list: the next searches of this index start with one (a repeat pass
+    // is a scan of the whole corpus for a handful of queries: at 1M rows a dozen repeated queries of 6980 cost 40 % of the
+    // search, a list x1.25 a few per cent)
+    if (ix->force_kc == 0 && nq >= 64 && (int64_t)flagged.size() * 1000 > nq) {
         if (kc < kc_max) ix->kc_boost = std::min(128, ix->kc_boost + (ix->kc_boost + 3) / 4);    // x1.25: 8, 10, 13, 17, 22, ...
         else if (qparts == 1 && ix->query_parts == 0) ix->parts_boost = true;
     }
