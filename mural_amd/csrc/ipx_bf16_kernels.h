@@ -949,19 +949,19 @@ rescore_kernel(const RescoreParams p) {
         const int64_t myrow = lane < 16 ? cI[my] - p.id_base : 0;
         const int mysw = (int)(((myrow % R) >> 2) & 3);
         float acc = 0.f;
-        uint4 v[RS_KB];
-#pragma unroll
-        for (int u = 0; u < RS_KB; ++u) v[u] = *(const uint4*)(src + (size_t)(u < p.nks ? u : p.nks - 1) * ks_stride);
+        // (four named registers, not an array: hipcc kept an array that is live across the loop in scratch memory)
+        static_assert(RS_KB == 4, "the prefetch below is written out for four K-stages per round");
+        const int last = p.nks - 1;
+        auto fetch = [&](int ks) { return *(const uint4*)(src + (size_t)(ks < last ? ks : last) * ks_stride); };
+        uint4 v0 = fetch(0), v1 = fetch(1), v2 = fetch(2), v3 = fetch(3);
         for (int ks0 = 0; ks0 < p.nks; ks0 += RS_KB) {
-#pragma unroll
-            for (int u = 0; u < RS_KB; ++u) *(uint4*)(stage + (u * 16 + r) * RS_ROW + pc * 16) = v[u];
-            if (ks0 + RS_KB < p.nks) {                     // the next group is on its way while this one is multiplied
-#pragma unroll
-                for (int u = 0; u < RS_KB; ++u) {
-                    const int ks = ks0 + RS_KB + u < p.nks ? ks0 + RS_KB + u : p.nks - 1;
-                    v[u] = *(const uint4*)(src + (size_t)ks * ks_stride);
-                }
-            }
+            *(uint4*)(stage + (0 * 16 + r) * RS_ROW + pc * 16) = v0;
+            *(uint4*)(stage + (1 * 16 + r) * RS_ROW + pc * 16) = v1;
+            *(uint4*)(stage + (2 * 16 + r) * RS_ROW + pc * 16) = v2;
+            *(uint4*)(stage + (3 * 16 + r) * RS_ROW + pc * 16) = v3;
+            // the next group is on its way while this one is multiplied (past the end: a harmless re-read of the
+            // last stage)
+            v0 = fetch(ks0 + 4); v1 = fetch(ks0 + 5); v2 = fetch(ks0 + 6); v3 = fetch(ks0 + 7);
             wave_lds_sync();
             if (lane < 16) {
                 const int nb = p.nks - ks0 < RS_KB ? p.nks - ks0 : RS_KB;

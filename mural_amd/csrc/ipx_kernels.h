@@ -705,6 +705,13 @@ scan_f32_kernel(const ScanParams p) {
         for (int ks = 0; ks < p.nks; ++ks, ++g) {
             const char* buf = smem + (g & 1) * STAGE_BYTES;
             const char* nbuf = smem + ((g + 1) & 1) * STAGE_BYTES;
+            // Set 0 was read from LDS half a stage ago (32 MFMAs back): it has landed. Saying so here — a wait that
+            // costs nothing, whose outputs the compiler takes as freshly defined — keeps hipcc from waiting for ALL
+            // outstanding LDS reads, the six reads of set 1 just below included, in front of the first MFMA on set 0
+            // (its counter state at the loop header is the join of two paths, and it falls back to lgkmcnt(0) there:
+            // found in the ISA in round 3; 663.8 -> 657.1 ms on the headline workload, same box, interleaved).
+            if constexpr (NJ == 4)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]));
 #pragma unroll
             for (int i = 0; i < 2; ++i) a1[i] = *(const f32x4*)(buf + a_off + i * 2048 + pc1);
 #pragma unroll
