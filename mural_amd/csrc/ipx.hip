@@ -10,12 +10,14 @@
 #include "ipx_bf16_w16_kernels.h"
 // The default library ships ONE large-batch bf16 scan (the 16-wave kernel, 2-deep ring: 16x16x32 MFMA with one query
 // part, 32x32x16 with hi + lo parts). The kernels and kernel variants that were built to find it and never won — the
-// 8-wave tile, the ping-pong and direct-corpus-operand kernels, deeper rings, issue orders, workgroup maps — only exist
+// 8-wave tile, the ping-pong and direct-corpus-operand kernels, the 384 x 256 tile on 12 waves, deeper rings, issue
+// orders, workgroup maps — only exist
 // in a -DIPX_DIAG build (libipx_diag.so: __graft_entry__.build_diag(), used by scripts/), where the "bf16_*" knobs of
 // ipx_set_param select them.
 #ifdef IPX_DIAG
 #include "ipx_bf16_pp_kernels.h"
 #include "ipx_bf16_dx_kernels.h"
+#include "ipx_bf16_w12_kernels.h"
 #endif
 #include <algorithm>
 #include <cstdio>
@@ -715,7 +717,17 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     const int bq = small ? 64 : 256;
     const int stage_b = bq * 64 * qparts;
     const int nqb = (int)((nq + bq - 1) / bq);
-    const int ntiles = (int)((N + ipx::HBD - 1) / ipx::HBD);
+    // large batches, one query part: the 12-wave kernel on 384-row tiles (ipx_bf16_w12_kernels.h)
+#ifdef IPX_DIAG
+    const bool w12 = !small && !deep && qparts == 1 && ix->bf16_pp == 0 && ix->bf16_waves == 12;
+    constexpr int w12_rows = ipx::XCfgBase::TD, w12_threads = ipx::XCfgBase::THREADS;
+    const int w12_ring = ix->bf16_ring == 3 ? ipx::XCfg<3>::RING : ipx::XCfg<2>::RING;
+#else
+    constexpr bool w12 = false;
+    constexpr int w12_rows = ipx::HBD, w12_threads = 0, w12_ring = 0;
+#endif
+    const int tile_rows = w12 ? w12_rows : ipx::HBD;
+    const int ntiles = (int)((N + tile_rows - 1) / tile_rows);
     // large batches, one query part: the 16-wave kernel, whose ring depth (and with a 64-KiB ring its workgroups per
     // CU) can be chosen
     const bool w16_1 = !small && (deep || (ix->bf16_pp == 0 &&
@@ -725,7 +737,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     // 93 ms with four — the workgroups that stream the same corpus split then keep each other in step through L2
     // (a workgroup that runs ahead misses L2 and waits on HBM, its followers hit), L2 fetch traffic per launch
     // halves (396 -> 170-190 GB) and the chip holds 2.06 instead of 1.82 GHz.
-    const int w16_ring = deep ? 2 : w16_1 && ix->bf16_ring != 4 ? ix->bf16_ring : 0;   // 0 = the four-deep ring of WCfg
+    const int w16_ring = deep ? 2 : w16_1 && !w12 && ix->bf16_ring != 4 ? ix->bf16_ring : 0;   // 0 = the four-deep ring of WCfg
     const int occ = (w16_ring == 2 && qparts == 1 && ix->bf16_occ == 2 && !deep) ? 2 : 1;
     const int resident = occ * ix->num_cus;                 // one workgroup per CU (two with the 64-KiB ring, if asked)
     int S = std::max(1, resident / nqb);
@@ -735,13 +747,14 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     const int nruns = (ntiles + R - 1) / R;
     S = std::min(S, nruns);
     const int G = nqb * S;
-    const bool w16k = !small && (deep || ((ix->bf16_waves == 16 || ix->bf16_waves == 0) && ix->bf16_pp == 0));
+    const bool w16k = !small && (deep || w12 || ((ix->bf16_waves == 16 || ix->bf16_waves == 0) && ix->bf16_pp == 0));
     // queue: kc survivors of a compaction + 2 tiles of appends before the next one runs + room to fill, rounded up to a
     // power of two (a capacity cut to the next multiple of 512 was measured at kc = 3000: 5120 instead of 8192 slots
     // gives the selections two more waves but forces extra episodes — 176 vs 146 ms of scan)
-    const int cap = next_pow2(kc + 2 * ipx::HBD + kc / 2);
+    // (the 12-wave kernel: two 384-row tiles of appends; a multiple of 512 is all its selections need)
+    const int cap = w12 ? (kc + 2 * w12_rows + kc / 2 + 511) / 512 * 512 : next_pow2(kc + 2 * ipx::HBD + kc / 2);
     const int cap_sort = next_pow2(cap);
-    const int ring = small ? (qparts == 2 ? ipx::HCfg<1, 2>::RING : ipx::HCfg<1, 1>::RING)
+    const int ring = w12 ? w12_ring : small ? (qparts == 2 ? ipx::HCfg<1, 2>::RING : ipx::HCfg<1, 1>::RING)
                      : w16_ring == 2 ? (qparts == 2 ? ipx::WCfg<2, 2>::RING : ipx::WCfg<1, 2>::RING)
                      : (w16_ring == 3 && qparts == 1) ? ipx::WCfg<1, 3>::RING
                            : (qparts == 2 ? ipx::HCfg<4, 2>::RING : ipx::HCfg<4, 1>::RING);
@@ -749,7 +762,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
     // is its own) 157 KiB whatever the ring depth
     const int sort_bytes = w16k && occ == 1 ? std::max(ring, 157 * 1024) : ring;
     const int nsortwaves = deep ? 0 : std::max(1, std::min(8, sort_bytes / (cap_sort * 8)));
-    const int nselect = w16k ? std::max(1, std::min(16, sort_bytes / ((cap + ipx::W16_SEL_AUX) * 4))) : 0;
+    const int nselect = w16k ? std::max(1, std::min(w12 ? 12 : 16, sort_bytes / ((cap + ipx::W16_SEL_AUX) * 4))) : 0;
 
     if (int rc = ix->Qp.ensure((size_t)nqb * nks * stage_b)) return rc;
     if (int rc = ix->cand.ensure((size_t)G * bq * cap * sizeof(uint64_t))) return rc;
@@ -819,7 +832,7 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
         // large batches: the 16-wave kernel (8.8M x 768, 6980 queries, one query part: 93 vs 102 ms for the 8-wave
         // kernel at the same ring depth; hi + lo parts at depth 1000, whole search: 197 ms with the 2-deep ring, 203
         // with 3, 217 on 8 waves)
-        const bool w16 = !small && (deep || ix->bf16_waves == 16 || ix->bf16_waves == 0);
+        const bool w16 = !small && !w12 && (deep || ix->bf16_waves == 16 || ix->bf16_waves == 0);
 #ifdef IPX_DIAG
         void (*kern)(const ipx::ScanParams, const int) =
             small ? (qparts == 2 ? ipx::scan_bf16_kernel<1, 2> : ipx::scan_bf16_kernel<1, 1>)
@@ -848,8 +861,11 @@ int bf16_pass(ipx_index* ix, const float* qf, int64_t nq, int k, int kc, int qpa
             small ? (qparts == 2 ? ipx::scan_bf16_kernel<1, 2> : ipx::scan_bf16_kernel<1, 1>)
                   : (qparts == 2 ? ipx::scan_bf16_w16_kernel<2, false, 0, false, 2> : ipx::scan_bf16_w16_kernel<1, true, 0, false, 2>);
 #endif
+#ifdef IPX_DIAG
+        if (w12) kern = ix->bf16_ring == 3 ? ipx::scan_bf16_w12_kernel<3> : ipx::scan_bf16_w12_kernel<2>;
+#endif
         if (int rc = ensure_dynamic_lds((const void*)kern, std::max(lds, 64 * 1024 + 1))) return rc;
-        hipLaunchKernelGGL(kern, dim3(G), dim3((pp || dx) ? 512 : w16 ? 1024 : ipx::HTHREADS), lds, st, p, nsortwaves);
+        hipLaunchKernelGGL(kern, dim3(G), dim3((pp || dx) ? 512 : w12 ? w12_threads : w16 ? 1024 : ipx::HTHREADS), lds, st, p, nsortwaves);
     }
     IPX_HIP(hipGetLastError());
     if (timing) IPX_HIP(hipEventRecord(ix->ev[2], st));
@@ -1837,7 +1853,7 @@ int ipx_set_param(ipx_index* ix, const char* name, int64_t value) {
         return 0;
     }
     if (!strcmp(name, "bf16_waves")) {
-        if (value != 0 && value != 8 && value != 16) return fail(IPX_ERR_ARG, "set_param: bf16_waves must be 0, 8 or 16");
+        if (value != 0 && value != 8 && value != 12 && value != 16) return fail(IPX_ERR_ARG, "set_param: bf16_waves must be 0, 8, 12 or 16");
         ix->bf16_waves = (int)value;
         return 0;
     }

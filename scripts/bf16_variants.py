@@ -47,6 +47,8 @@ for spec in os.environ.get("VARIANTS", "map1;v1;v2;v3;v4;map1,v1;map1,v2;map1,v3
             prm["bf16_variant"] = int(tok[1:])
         elif tok == "w8":
             prm["bf16_waves"] = 8
+        elif tok == "w12":
+            prm["bf16_waves"] = 12
         elif tok == "s16":
             prm["bf16_shape16"] = 1
         elif tok == "s32":

@@ -389,7 +389,7 @@ def test_outlier_rows_are_scored_on_the_side(R, n, d, nq, k, adds, nout):
     if nq > 64:
         variants = [{"query_parts": 2}, {"no_small_batch": 1, "max_splits": 1}]
         if diag_build():
-            variants += [{"bf16_waves": 8}, {"bf16_pp": 1}, {"bf16_pp": 3}, {"bf16_shape16": 0}]
+            variants += [{"bf16_waves": 8}, {"bf16_waves": 12}, {"bf16_pp": 1}, {"bf16_pp": 3}, {"bf16_shape16": 0}]
         for prm in variants:
             for key, val in prm.items():
                 ix.set_param(key, val)
@@ -486,7 +486,7 @@ def test_large_batch_scan_variants_return_the_same_bits(R, n, d, nq, k):
             if diag_build():
                 variants += [{"bf16_ring": 3}, {"bf16_ring": 4, "bf16_map": 2}, {"bf16_ring": 2, "bf16_map": 7}, {"bf16_ring": 2, "bf16_occ": 2},
                              {"bf16_shape16": 0}, {"bf16_shape16": 0, "bf16_variant": 2}, {"bf16_shape16": 0, "bf16_variant": 3},
-                             {"bf16_shape16": 0, "bf16_variant": 5, "bf16_map": 1}, {"bf16_waves": 8}, {"bf16_pp": 1},
+                             {"bf16_shape16": 0, "bf16_variant": 5, "bf16_map": 1}, {"bf16_waves": 8}, {"bf16_waves": 12}, {"bf16_waves": 12, "bf16_ring": 3}, {"bf16_pp": 1},
                              {"bf16_pp": 2, "bf16_map": 1}, {"bf16_pp": 3, "bf16_map": 3}, {"bf16_pp": 4}]
             for prm in variants:
                 for key, val in {"bf16_shape16": 1, "bf16_variant": 0, "bf16_map": 0, "bf16_waves": 0, "bf16_pp": 0, "bf16_ring": 0,
