@@ -525,10 +525,53 @@ __device__ __forceinline__ void issue_stage(const ScanParams& p, char* buf, int6
 #undef IPX_GLDS
 }
 
+// The same six pieces, each issued from asm in the scalar-base form: M0 = the piece's LDS address, base in scalar
+// registers, the lane's 16 bytes as a 32-bit offset. Piece i of 0..5: 0, 1 = corpus, 2..5 = queries.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"     // m0 on a clobber list (the copy pieces set it themselves)
+struct StagePiecesF32 {
+    const char* ga;
+    const char* gb;
+    uint32_t la, lb;
+    static __device__ __forceinline__ const char* uniform_ptr(const char* ptr) {
+        const uint64_t v = (uint64_t)(uintptr_t)ptr;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    }
+    __device__ __forceinline__ StagePiecesF32(const ScanParams& p, uint32_t lds_buf, int64_t tile, int qb, int ks, int wave) {
+        ga = uniform_ptr((const char*)p.Xp + ((size_t)tile * p.nks + ks) * STAGE_A_BYTES + wave * 2048);
+        gb = uniform_ptr((const char*)p.Qp + ((size_t)qb * p.nks + ks) * STAGE_B_BYTES + wave * 4096);
+        la = __builtin_amdgcn_readfirstlane(lds_buf + wave * 2048);
+        lb = __builtin_amdgcn_readfirstlane(lds_buf + STAGE_A_BYTES + wave * 4096);
+    }
+    template <int I>
+    __device__ __forceinline__ void issue(uint32_t lane16) const {
+        const char* g = I < 2 ? ga + I * 1024 : gb + (I - 2) * 1024;
+        const uint32_t l = I < 2 ? la + I * 1024 : lb + (I - 2) * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(l), "v"(lane16), "s"(g) : "memory", "m0");
+    }
+};
+#pragma clang diagnostic pop
+
 // A stage of the scan: K-stage `ks` of corpus tile `t`; ok == false marks "past the end" (the
 // pipeline still issues a copy for it, into a buffer nobody reads, so the loop has no branches).
 struct StageCursor { int t, ks; bool ok; };
 
+// IPX_F32_ABL (ablation builds for measurement only — results are wrong; scripts/f32_ablation.sh): bit 0 = no stage
+// barrier, bit 1 = no epilogue filter, bit 2 = no copy pieces in the loop, bit 3 = no episodes, bit 4 = no vmcnt wait,
+// bit 5 = every query parked (the filter runs and never passes), bit 6 = accumulators not zeroed per tile.
+#ifndef IPX_F32_ABL
+#define IPX_F32_ABL 0
+#endif
+// IPX_F32_OPT (A/B builds; every combination returns the same bits): bit 0 = the filter's hit path votes on eight
+// 4-register groups before it looks at single registers, bit 1 = the copy pieces of the stage loop are issued from asm
+// in the scalar-base form (no per-lane 64-bit address arithmetic: a VALU instruction in this loop is not hidden behind
+// the other workgroup's MFMAs), bit 2 = accumulators zeroed two registers per instruction.
+// (Measured and dropped in round 3: a tile's first MFMAs taking a zero C operand from a peeled first stage — 659.2 vs
+// 656.5 ms; the two workgroups of a CU running their scheduled episodes at different tile counts — no difference.)
+#ifndef IPX_F32_OPT
+#define IPX_F32_OPT 7
+#endif
 // DEEP: lists beyond IPX_MAX_K entries (ScanParams::deepK): the episodes' selections take 4 bytes of LDS per queue slot
 // + a side list, on p.nselect waves; the final pass writes each split's best k keys unsorted (deep_finish_kernel sorts).
 // The hot loop is the same code; the headline instantiation <false, false> is untouched by it.
@@ -604,7 +647,7 @@ scan_f32_kernel(const ScanParams p) {
     // thresholds: -FLT_MAX is faiss's heap neutral (scores must be > it to enter);
     // +inf parks the padding queries of the last block.
     cnts[tid] = 0;
-    taus[tid] = ((int64_t)qb * BQ + tid < p.nq) ? -FLT_MAX : INFINITY;
+    taus[tid] = (!(IPX_F32_ABL & 32) && (int64_t)qb * BQ + tid < p.nq) ? -FLT_MAX : INFINITY;
     if (tid < 2) flags[tid] = 0;
     uint32_t* mypub = (p.S > 1 && !helper) ? p.pub + ((size_t)qb * p.S + split) * BQ : nullptr;
     if (helper) {
@@ -616,6 +659,8 @@ scan_f32_kernel(const ScanParams p) {
     uint64_t* scratch = (uint64_t*)smem + (size_t)wave * p.cap;
 
     const int sw = (lane >> 2) & 3;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t lane16 = (uint32_t)lane * 16;
     const int a_off = (wd * 64 + l31) * 64;     // byte offset of this lane's doc row in a stage
     // Query groups of 32 are dealt to the two wave columns alternately (group 2j + wq is wave column wq's j-th), so
     // the live groups of a ragged last block spread over both columns.
@@ -695,12 +740,36 @@ scan_f32_kernel(const ScanParams p) {
         const int t = c0.t;
         if (t == enter_t) claim_next_run();
         f32x16 acc[2][4];
+        if constexpr ((IPX_F32_ABL & 64) != 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" : "=v"(acc[i][j]));
+        } else if constexpr ((IPX_F32_OPT & 4) != 0) {
+            // two registers per instruction (a VALU instruction at a tile boundary is not hidden behind the other
+            // workgroup's MFMAs: the 128 v_mov_b32 were measured at 0.5 % of the launch)
+            typedef uint64_t u64x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    u64x8 z;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        uint64_t ze;
+                        asm volatile("v_mov_b64 %0, 0" : "=v"(ze));
+                        z[e] = ze;
+                    }
+                    acc[i][j] = __builtin_bit_cast(f32x16, z);
+                }
+        } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
 
         for (int ks = 0; ks < p.nks; ++ks, ++g) {
             const char* buf = smem + (g & 1) * STAGE_BYTES;
@@ -732,11 +801,40 @@ scan_f32_kernel(const ScanParams p) {
             // keep the 32 MFMAs above the barrier (hipcc would sink them below it and expose
             // the LDS read latency of set 1)
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if constexpr (!(IPX_F32_ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (!(IPX_F32_ABL & 1)) __syncthreads();
+            if constexpr (NJ == 4 && (IPX_F32_OPT & 2) != 0 && !(IPX_F32_ABL & 4)) {
+                // MFMAs start at once; the six copy pieces go out from asm, one behind every second MFMA, in source
+                // order (the scheduler does not move what it cannot see into); then, as below, the six LDS reads of
+                // the next stage's set 0 between pairs of MFMAs
+                const StagePiecesF32 sp(p, smem_base + (g & 1) * STAGE_BYTES, c2.t, qb, c2.ks, wave);
+#define IPX_F32_MF(N_) acc[((N_) >> 2) & 1][(N_) & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32( \
+                    a1[((N_) >> 2) & 1][(N_) >> 3], b1[(N_) & 3][(N_) >> 3], acc[((N_) >> 2) & 1][(N_) & 3], 0, 0, 0)
+                IPX_F32_MF(0); IPX_F32_MF(1); sp.template issue<0>(lane16); __builtin_amdgcn_sched_barrier(0);
+                IPX_F32_MF(2); IPX_F32_MF(3); sp.template issue<1>(lane16); __builtin_amdgcn_sched_barrier(0);
+                IPX_F32_MF(4); IPX_F32_MF(5); sp.template issue<2>(lane16); __builtin_amdgcn_sched_barrier(0);
+                IPX_F32_MF(6); IPX_F32_MF(7); sp.template issue<3>(lane16); __builtin_amdgcn_sched_barrier(0);
+                IPX_F32_MF(8); IPX_F32_MF(9); sp.template issue<4>(lane16); __builtin_amdgcn_sched_barrier(0);
+                IPX_F32_MF(10); IPX_F32_MF(11); sp.template issue<5>(lane16); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a0[i] = *(const f32x4*)(nbuf + a_off + i * 2048 + pc0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b0[j] = *(const f32x4*)(nbuf + b_off + j * 4096 + pc0);
+                IPX_F32_MF(12); IPX_F32_MF(13); IPX_F32_MF(14); IPX_F32_MF(15); IPX_F32_MF(16); IPX_F32_MF(17);
+                IPX_F32_MF(18); IPX_F32_MF(19); IPX_F32_MF(20); IPX_F32_MF(21); IPX_F32_MF(22); IPX_F32_MF(23);
+                IPX_F32_MF(24); IPX_F32_MF(25); IPX_F32_MF(26); IPX_F32_MF(27); IPX_F32_MF(28); IPX_F32_MF(29);
+                IPX_F32_MF(30); IPX_F32_MF(31);
+#undef IPX_F32_MF
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            } else {
             // No branches from here to the end of the stage, so hipcc can spread the copy
             // issue and the LDS reads among the 32 MFMAs.
-            issue_stage(p, smem + (g & 1) * STAGE_BYTES, c2.t, qb, c2.ks, wave, lane);
+            if constexpr (!(IPX_F32_ABL & 4)) issue_stage(p, smem + (g & 1) * STAGE_BYTES, c2.t, qb, c2.ks, wave, lane);
 #pragma unroll
             for (int i = 0; i < 2; ++i) a0[i] = *(const f32x4*)(nbuf + a_off + i * 2048 + pc0);
 #pragma unroll
@@ -763,6 +861,7 @@ scan_f32_kernel(const ScanParams p) {
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
+            }
             __builtin_amdgcn_sched_barrier(0);
             c0 = c1;
             c1 = c2;
@@ -778,39 +877,59 @@ scan_f32_kernel(const ScanParams p) {
         // value (a tile's barriers lie between those writes and this read; this tile writes the other)
         bool episode = lds_read_i32_nodma(&flags[(tiles_done + 1) & 1]) != 0;
         int* myflag = &flags[tiles_done & 1];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int ql = (2 * j + wq) * 32 + l31;
-            const float tau = lds_read_f32_nodma(&taus[ql]);
-            float m = acc[0][j][0];
+        if constexpr ((IPX_F32_ABL & 2) != 0) {          // (keeps the accumulators alive without the filter)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+                for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(acc[i][j]));
+        }
+#pragma unroll
+        for (int j = 0; j < ((IPX_F32_ABL & 2) ? 0 : NJ); ++j) {
+            const int ql = (2 * j + wq) * 32 + l31;
+            const float tau = lds_read_f32_nodma(&taus[ql]);
+            // this lane's maximum over its 32 scores of the query, kept per group of four registers (four consecutive rows)
+            float g8[8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    g8[i * 4 + q4] = fmaxf(fmaxf(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1]), fmaxf(acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]));
+            float m = g8[0];
+#pragma unroll
+            for (int u = 1; u < 8; ++u) m = fmaxf(m, g8[u]);
             if (__any(m > tau)) {
-                // Rare per element, but some lane of the wave passes on many tiles: branch per
-                // register on the wave-wide vote, so registers nobody passes in cost one compare.
+                // Rare per element, but some lane of the wave passes on many tiles (measured, round 3: the hit path +
+                // the episodes it feeds cost 2.8 % of the launch, the filter above 0.7 %): wave-wide votes, first per
+                // group of four registers, then per register of a group somebody passes in — registers nobody passes
+                // in cost a quarter of a compare + branch (round 1-2 voted on all 32 registers).
                 uint64_t* qu = myqueues + (size_t)ql * p.cap;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float sc = acc[i][j][r];
-                        if (__any(sc > tau)) {
-                            const int64_t doc = docbase + i * 32 + (r & 3) + 8 * (r >> 2);
-                            bool admit = sc > tau && doc < p.N;
-                            if constexpr (CEIL) {
-                                if (admit) {        // (padding queries never get here: their tau is +inf)
-                                    const int64_t cid = p.ceilI[(int64_t)qb * BQ + ql];
-                                    admit = cid >= 0 && make_key(sc, (uint32_t)doc) <
-                                                            make_key(p.ceilD[(int64_t)qb * BQ + ql], (uint32_t)(cid - p.id_base));
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        if constexpr ((IPX_F32_OPT & 1) != 0) {
+                            if (!__any(g8[i * 4 + q4] > tau)) continue;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * q4 + e;
+                            const float sc = acc[i][j][r];
+                            if (__any(sc > tau)) {
+                                const int64_t doc = docbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                                bool admit = sc > tau && doc < p.N;
+                                if constexpr (CEIL) {
+                                    if (admit) {        // (padding queries never get here: their tau is +inf)
+                                        const int64_t cid = p.ceilI[(int64_t)qb * BQ + ql];
+                                        admit = cid >= 0 && make_key(sc, (uint32_t)doc) <
+                                                                make_key(p.ceilD[(int64_t)qb * BQ + ql], (uint32_t)(cid - p.id_base));
+                                    }
                                 }
-                            }
-                            if (admit) {
-                                const int pos = lds_atomic_inc_nodma(&cnts[ql]);
-                                if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
-                                else *p.err = 1;
-                                if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
+                                if (admit) {
+                                    const int pos = lds_atomic_inc_nodma(&cnts[ql]);
+                                    if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
+                                    else *p.err = 1;
+                                    if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
+                                }
                             }
                         }
                     }
@@ -823,6 +942,7 @@ scan_f32_kernel(const ScanParams p) {
         //  * a threshold poll alone after 8, 32, 128, ... tiles, when the other splits' values
         //    of the previous round are there.
         episode = episode || is_pow4(tiles_done);
+        if constexpr ((IPX_F32_ABL & 8) != 0) episode = false;
         if (episode) {
             // The sort scratch aliases both stage buffers, which hold stage c0 (landed; its
             // set-0 operands are already in registers) and stage c1 (in flight): let the
