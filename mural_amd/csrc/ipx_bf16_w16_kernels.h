@@ -23,27 +23,43 @@ template <int QP, int NB = 0> struct WCfg {
     static constexpr int RING = NBUF * STAGE;
 };
 
-#define IPX_GLDS_NT(g_, l_) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g_), \
-                                                              (__attribute__((address_space(3))) void*)(l_), 16, 0, 2)
+// The copy pieces of one stage, issued from asm in the scalar-base form: M0 = the piece's LDS address, base in scalar
+// registers, the lane's 16 bytes as a 32-bit offset — no per-lane 64-bit address arithmetic in the stage loop (round 3:
+// on the fp32 scan the same change was worth 1.5 %; a VALU instruction in an MFMA-bound loop is not free).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"     // m0 on a clobber list (the copy pieces set it themselves)
 template <int QP, bool NT = false>
 struct WPieces {
     const char* ga;
     const char* gb;
-    char* la;
+    uint32_t la;
+    uint32_t lane16;
+    static __device__ __forceinline__ const char* uniform_ptr(const char* ptr) {
+        const uint64_t v = (uint64_t)(uintptr_t)ptr;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    }
     __device__ __forceinline__ WPieces(const ScanParams& p, char* buf, int64_t tile, int qb, int ks, int wave, int lane) {
-        ga = (const char*)p.Xp + ((size_t)tile * p.nks + ks) * HSTAGE_A + wave * 1024 + lane * 16;
-        gb = (const char*)p.Qp + ((size_t)qb * p.nks + ks) * (WCfg<QP>::PART_B * QP) + wave * 1024 + lane * 16;
-        la = buf + wave * 1024;
+        ga = uniform_ptr((const char*)p.Xp + ((size_t)tile * p.nks + ks) * HSTAGE_A + wave * 1024);
+        gb = uniform_ptr((const char*)p.Qp + ((size_t)qb * p.nks + ks) * (WCfg<QP>::PART_B * QP) + wave * 1024);
+        la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)buf + wave * 1024);
+        lane16 = (uint32_t)lane * 16;
     }
-    __device__ __forceinline__ void issue_a() const {
-        if constexpr (NT) IPX_GLDS_NT(ga, la); else IPX_GLDS(ga, la);
+    template <bool NT_>
+    static __device__ __forceinline__ void piece(const char* g, uint32_t l, uint32_t voff) {
+        if constexpr (NT_)
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2 nt" :: "s"(l), "v"(voff), "s"(g) : "memory", "m0");
+        else
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(l), "v"(voff), "s"(g) : "memory", "m0");
     }
+    __device__ __forceinline__ void issue_a() const { piece<NT>(ga, la, lane16); }
     __device__ __forceinline__ void issue_b() const {
-        IPX_GLDS(gb, la + HSTAGE_A);
-        if constexpr (QP == 2) IPX_GLDS(gb + WCfg<QP>::PART_B, la + HSTAGE_A + WCfg<QP>::PART_B);
+        piece<false>(gb, la + HSTAGE_A, lane16);
+        if constexpr (QP == 2) piece<false>(gb + WCfg<QP>::PART_B, la + HSTAGE_A + WCfg<QP>::PART_B, lane16);
     }
     __device__ __forceinline__ void issue_all() const { issue_a(); issue_b(); }
 };
+#pragma clang diagnostic pop
 
 __device__ __forceinline__ void w16_wait4(f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");

@@ -390,17 +390,164 @@ __device__ __forceinline__ uint32_t nth_largest_lds(const uint32_t* sh, int kpl8
     return t;
 }
 
+// wave-wide max / min of a 32-bit value (every lane gets the result)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off); v = o < v ? o : v; }
+    return v;
+}
+
+// nth_largest_lds for a queue of at most 512 entries held in REGISTERS (x[u] = entry lane + 64 u, 0 = empty slot): the
+// same two levels, but the steps over all entries read no memory, and they start below the entries' common prefix —
+// vmax / vmin are the largest and smallest non-empty entry (wave-uniform): every entry, so the answer too, shares
+// their common leading bits (scores of one candidate list lie close together: sign and exponent, 8-9 steps of 32).
+// Measured in round 3 on the headline scan: a selection over LDS took ~29 us (a wave beside MFMA-bound waves gets an
+// instruction through every ~40 cycles: what counts is the number of instructions), two per query and episode,
+// 4.5 % of a workgroup's time in episodes. need in [1, number of non-empty entries].
+__device__ __forceinline__ uint32_t nth_largest_regs8(const uint32_t (&x)[8], int lane, int need, uint32_t vmax, uint32_t vmin,
+                                                      uint32_t* aux, int aux_cap) {
+    if (vmax == vmin) return vmax;
+    const int hb = 31 - __builtin_clz(vmax ^ vmin);               // highest bit in which two entries differ
+    uint32_t t = hb >= 31 ? 0u : (vmax >> (hb + 1)) << (hb + 1);  // the common prefix
+    int b = hb;
+#pragma unroll 1
+    for (; b >= 16; --b) {
+        const uint32_t cand = t | (1u << b);
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cnt += __popcll(__ballot(x[u] >= cand));
+        if (cnt >= need) t = cand;
+    }
+    // bits 31..16 are decided (or common): the entries that share them go to the side list
+    const uint32_t top = t >> 16;
+    int above = 0, m = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const bool match = (x[u] >> 16) == top;
+        above += __popcll(__ballot((x[u] >> 16) > top));
+        const uint64_t mask = __ballot(match);
+        const int at = m + __popcll(mask & ((1ull << lane) - 1));
+        if (match && at < aux_cap) aux[at] = x[u];
+        m += __popcll(mask);
+    }
+    if (m > aux_cap) {                         // the bucket is too large for the side list: all entries again
+#pragma unroll 1
+        for (; b >= 0; --b) {
+            const uint32_t cand = t | (1u << b);
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cnt += __popcll(__ballot(x[u] >= cand));
+            if (cnt >= need) t = cand;
+        }
+        return t;
+    }
+    wave_lds_sync();
+    const int need2 = need - above;
+    const int rounds = (m + 63) >> 6;
+#pragma unroll 1
+    for (; b >= 0; --b) {
+        const uint32_t cand = t | (1u << b);
+        int cnt = 0;
+#pragma unroll 1
+        for (int j = 0; j < rounds; ++j) {
+            const int i = lane + 64 * j;
+            const uint32_t y = i < m ? aux[i] : 0u;
+            cnt += __popcll(__ballot(y >= cand));
+        }
+        if (cnt >= need2) t = cand;
+    }
+    wave_lds_sync();                           // the side list is free again
+    return t;
+}
+
 // `aux` / `aux_cap`: the selections' side list; nullptr = the second half of a scratch of 8 bytes per queue slot.
 __device__ __forceinline__ void compact_query_select(const ScanParams& p, uint64_t* scratch, int* cnts, float* taus,
                                                      uint64_t* queue, int ql, int lane, uint32_t* pub_slot,
-                                                     uint32_t* aux = nullptr, int aux_cap = 0) {
+                                                     uint32_t* aux = nullptr, int aux_cap = 0, uint64_t* tph = nullptr) {
     if (!aux) { aux = (uint32_t*)scratch + p.cap; aux_cap = p.cap; }
+#ifdef IPX_F32_TRACE_HITS
+    uint64_t tp0 = __builtin_amdgcn_s_memrealtime(), tp1;
+#define IPX_TPH(I_) if (tph) { tp1 = __builtin_amdgcn_s_memrealtime(); tph[I_] += tp1 - tp0; tp0 = tp1; }
+#else
+#define IPX_TPH(I_)
+#endif
     const int n = cnts[ql];
     const bool publish = pub_slot && n >= p.r;
     if (n <= p.k && !publish) return;
     const int kpl8 = (((n + 63) >> 6) + 7) & ~7;         // slots per lane, in batches of 8 (64 * kpl8 <= cap)
     uint32_t* sh = (uint32_t*)scratch;                    // [64 * kpl8] high words, later (in place) the low words of tied keys
     const uint32_t* q32 = (const uint32_t*)queue;
+    if (kpl8 == 8) {
+        // up to 512 entries (every episode of a top-100 search): the high words stay in registers
+        uint32_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = lane + 64 * u;
+            x[u] = q32[2 * (i < n ? i : n - 1) + 1];
+        }
+        uint32_t lmax = 0, lmin = 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool valid = lane + 64 * u < n;
+            x[u] = valid ? x[u] : 0u;
+            lmax = x[u] > lmax ? x[u] : lmax;
+            lmin = valid && x[u] < lmin ? x[u] : lmin;
+        }
+        const uint32_t vmax = wave_max_u32(lmax), vmin = wave_min_u32(lmin);
+        IPX_TPH(0)
+        if (publish) {
+            const uint32_t vr = nth_largest_regs8(x, lane, p.r, vmax, vmin, aux, aux_cap);
+            if (lane == 0) __hip_atomic_store(pub_slot, vr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        IPX_TPH(1)
+        if (n <= p.k) return;
+        const uint32_t v = nth_largest_regs8(x, lane, p.k, vmax, vmin, aux, aux_cap);
+        IPX_TPH(2)
+        int above = 0, tied = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            above += __popcll(__ballot(x[u] > v));
+            tied += __popcll(__ballot(x[u] == v));
+        }
+        uint32_t lcut = 0;
+        if (tied > p.k - above) {              // ties at the cut (rare): the tied keys' low words, through LDS as below
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = lane + 64 * u;
+                sh[i] = (i < n && x[u] == v) ? q32[2 * i] : 0u;
+            }
+            wave_lds_sync();
+            lcut = nth_largest_lds(sh, 8, lane, p.k - above, aux, aux_cap);
+        }
+        int base = 0;
+        uint64_t key[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = lane + 64 * u;
+            key[u] = queue[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = lane + 64 * u;
+            const uint32_t h = (uint32_t)(key[u] >> 32);
+            const bool keep = i < n && (h > v || (h == v && (uint32_t)key[u] >= lcut));
+            const uint64_t mask = __ballot(keep);
+            if (keep) queue[base + __popcll(mask & ((1ull << lane) - 1))] = key[u];
+            base += __popcll(mask);
+        }
+        if (lane == 0) {
+            cnts[ql] = base;                          // == k
+            taus[ql] = fmaxf(taus[ql], f32_unordered(v));
+        }
+        wave_lds_sync();
+        IPX_TPH(3)
+        return;
+    }
 #pragma unroll 1
     for (int j0 = 0; j0 < kpl8; j0 += 8) {
         uint32_t x[8];
@@ -416,12 +563,15 @@ __device__ __forceinline__ void compact_query_select(const ScanParams& p, uint64
         }
     }
     wave_lds_sync();
+    IPX_TPH(0)
     if (publish) {
         const uint32_t vr = nth_largest_lds(sh, kpl8, lane, p.r, aux, aux_cap);
         if (lane == 0) __hip_atomic_store(pub_slot, vr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    IPX_TPH(1)
     if (n <= p.k) return;
     const uint32_t v = nth_largest_lds(sh, kpl8, lane, p.k, aux, aux_cap);      // >= 1: empty slots (0) never pass
+    IPX_TPH(2)
     // ties at the cut: only the (k - #above) tied keys with the largest low words survive
     int above = 0, tied = 0;
 #pragma unroll 1
@@ -467,6 +617,8 @@ __device__ __forceinline__ void compact_query_select(const ScanParams& p, uint64
         taus[ql] = fmaxf(taus[ql], f32_unordered(v));
     }
     wave_lds_sync();
+    IPX_TPH(3)
+#undef IPX_TPH
 }
 
 // Final pass of a deep list: the queue's best k keys (all of them if there are fewer), filtered by the threshold like
@@ -559,7 +711,8 @@ struct StageCursor { int t, ks; bool ok; };
 
 // IPX_F32_ABL (ablation builds for measurement only — results are wrong; scripts/f32_ablation.sh): bit 0 = no stage
 // barrier, bit 1 = no epilogue filter, bit 2 = no copy pieces in the loop, bit 3 = no episodes, bit 4 = no vmcnt wait,
-// bit 5 = every query parked (the filter runs and never passes), bit 6 = accumulators not zeroed per tile.
+// bit 5 = every query parked (the filter runs and never passes), bit 6 = accumulators not zeroed per tile,
+// bit 7 = hits are voted on but nothing is appended (so no episode is ever triggered by a queue).
 #ifndef IPX_F32_ABL
 #define IPX_F32_ABL 0
 #endif
@@ -569,8 +722,9 @@ struct StageCursor { int t, ks; bool ok; };
 // the other workgroup's MFMAs), bit 2 = accumulators zeroed two registers per instruction.
 // (Measured and dropped in round 3: a tile's first MFMAs taking a zero C operand from a peeled first stage — 659.2 vs
 // 656.5 ms; the two workgroups of a CU running their scheduled episodes at different tile counts — no difference.)
+// bit 3 = the stage loop unrolled by two when a tile has an even number of K-stages (no address VALU in the loop).
 #ifndef IPX_F32_OPT
-#define IPX_F32_OPT 7
+#define IPX_F32_OPT 15
 #endif
 // DEEP: lists beyond IPX_MAX_K entries (ScanParams::deepK): the episodes' selections take 4 bytes of LDS per queue slot
 // + a side list, on p.nselect waves; the final pass writes each split's best k keys unsorted (deep_finish_kernel sorts).
@@ -601,6 +755,10 @@ scan_f32_kernel(const ScanParams p) {
     bool helper = false;
     const int fill_limit = p.cap - 2 * BD;      // a set flag is acted on one tile later
     int tiles_done = 0, n_compact = 0;
+#ifdef IPX_F32_TRACE_HITS       // measurement build (scripts/trace_wgs.py): wave 0's hit groups, appends, ticks in episodes
+    uint32_t tr_hits = 0, tr_app = 0;
+    uint64_t tr_epi = 0, tr_ph[4] = {0, 0, 0, 0};
+#endif
     const int nqb = (p.nq + BQ - 1) / BQ;
     // Thread 0 picks the query block with the most runs left (starting the search at a block of this
     // workgroup's own, so simultaneous pickers spread out) and takes one of its spare output slots.
@@ -734,8 +892,12 @@ scan_f32_kernel(const ScanParams p) {
     int g = 0;
     // The tile loop, instantiated per number of live 32-query groups of this wave (NJ): the last query block of a
     // batch is usually ragged (6980 queries = 27 blocks + 68), and its all-padding groups are not multiplied.
-    auto scan_tiles = [&](auto nj_const) {
+    // EVEN (an even number of K-stages per tile, full blocks only): the stage loop is unrolled by two, so which of the
+    // two stage buffers a stage reads is known at compile time and goes into the LDS reads' immediate offsets — the
+    // loop then has no VALU instruction at all (the four address additions per stage were the last ones).
+    auto scan_tiles = [&](auto nj_const, auto even_tag) {
     constexpr int NJ = decltype(nj_const)::value;
+    constexpr bool EVEN = decltype(even_tag)::value && (IPX_F32_OPT & 8) != 0;
     while (c0.ok) {
         const int t = c0.t;
         if (t == enter_t) claim_next_run();
@@ -771,9 +933,12 @@ scan_f32_kernel(const ScanParams p) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         }
 
-        for (int ks = 0; ks < p.nks; ++ks, ++g) {
-            const char* buf = smem + (g & 1) * STAGE_BYTES;
-            const char* nbuf = smem + ((g + 1) & 1) * STAGE_BYTES;
+        // one K-stage; PAR = the buffer it reads (0 / 1), -1 = (g & 1), decided at run time
+        auto stage = [&](auto par_tag) {
+            constexpr int PAR = decltype(par_tag)::value;
+            const int par = PAR >= 0 ? PAR : (g & 1);
+            const char* buf = smem + par * STAGE_BYTES;
+            const char* nbuf = smem + (1 - par) * STAGE_BYTES;
             // Set 0 was read from LDS half a stage ago (32 MFMAs back): it has landed. Saying so here — a wait that
             // costs nothing, whose outputs the compiler takes as freshly defined — keeps hipcc from waiting for ALL
             // outstanding LDS reads, the six reads of set 1 just below included, in front of the first MFMA on set 0
@@ -807,7 +972,7 @@ scan_f32_kernel(const ScanParams p) {
                 // MFMAs start at once; the six copy pieces go out from asm, one behind every second MFMA, in source
                 // order (the scheduler does not move what it cannot see into); then, as below, the six LDS reads of
                 // the next stage's set 0 between pairs of MFMAs
-                const StagePiecesF32 sp(p, smem_base + (g & 1) * STAGE_BYTES, c2.t, qb, c2.ks, wave);
+                const StagePiecesF32 sp(p, smem_base + par * STAGE_BYTES, c2.t, qb, c2.ks, wave);
 #define IPX_F32_MF(N_) acc[((N_) >> 2) & 1][(N_) & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32( \
                     a1[((N_) >> 2) & 1][(N_) >> 3], b1[(N_) & 3][(N_) >> 3], acc[((N_) >> 2) & 1][(N_) & 3], 0, 0, 0)
                 IPX_F32_MF(0); IPX_F32_MF(1); sp.template issue<0>(lane16); __builtin_amdgcn_sched_barrier(0);
@@ -834,7 +999,7 @@ scan_f32_kernel(const ScanParams p) {
             } else {
             // No branches from here to the end of the stage, so hipcc can spread the copy
             // issue and the LDS reads among the 32 MFMAs.
-            if constexpr (!(IPX_F32_ABL & 4)) issue_stage(p, smem + (g & 1) * STAGE_BYTES, c2.t, qb, c2.ks, wave, lane);
+            if constexpr (!(IPX_F32_ABL & 4)) issue_stage(p, smem + par * STAGE_BYTES, c2.t, qb, c2.ks, wave, lane);
 #pragma unroll
             for (int i = 0; i < 2; ++i) a0[i] = *(const f32x4*)(nbuf + a_off + i * 2048 + pc0);
 #pragma unroll
@@ -866,6 +1031,15 @@ scan_f32_kernel(const ScanParams p) {
             c0 = c1;
             c1 = c2;
             c2 = advance(c2);
+            if constexpr (PAR < 0) ++g;
+        };
+        if constexpr (EVEN) {
+            for (int ks = 0; ks < p.nks; ks += 2) {
+                stage(std::integral_constant<int, 0>{});
+                stage(std::integral_constant<int, 1>{});
+            }
+        } else {
+            for (int ks = 0; ks < p.nks; ++ks) stage(std::integral_constant<int, -1>{});
         }
         // here c0 / c1 are the first two stages of the next tile of this workgroup (if any),
         // c0's set-0 operands are in registers, c1's copy is in flight
@@ -898,6 +1072,9 @@ scan_f32_kernel(const ScanParams p) {
 #pragma unroll
             for (int u = 1; u < 8; ++u) m = fmaxf(m, g8[u]);
             if (__any(m > tau)) {
+#ifdef IPX_F32_TRACE_HITS
+                ++tr_hits;
+#endif
                 // Rare per element, but some lane of the wave passes on many tiles (measured, round 3: the hit path +
                 // the episodes it feeds cost 2.8 % of the launch, the filter above 0.7 %): wave-wide votes, first per
                 // group of four registers, then per register of a group somebody passes in — registers nobody passes
@@ -924,6 +1101,13 @@ scan_f32_kernel(const ScanParams p) {
                                                                 make_key(p.ceilD[(int64_t)qb * BQ + ql], (uint32_t)(cid - p.id_base));
                                     }
                                 }
+                                if constexpr ((IPX_F32_ABL & 128) != 0) {
+                                    if (admit) asm volatile("" :: "v"(doc));
+                                    admit = false;
+                                }
+#ifdef IPX_F32_TRACE_HITS
+                                tr_app += (uint32_t)__popcll(__ballot(admit));
+#endif
                                 if (admit) {
                                     const int pos = lds_atomic_inc_nodma(&cnts[ql]);
                                     if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
@@ -947,8 +1131,12 @@ scan_f32_kernel(const ScanParams p) {
             // The sort scratch aliases both stage buffers, which hold stage c0 (landed; its
             // set-0 operands are already in registers) and stage c1 (in flight): let the
             // copy land, sort, then fetch both stages again.
+#ifdef IPX_F32_TRACE_HITS
+            const uint64_t tr_e0 = __builtin_amdgcn_s_memrealtime();
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if constexpr ((IPX_F32_OPT & 16) != 0) __builtin_amdgcn_s_setprio(3);
             ++n_compact;
             if (tid < 2) flags[tid] = 0;
             if constexpr (DEEP) {
@@ -960,26 +1148,38 @@ scan_f32_kernel(const ScanParams p) {
                 }
             } else {
                 for (int ql = wave; ql < BQ; ql += 4)
+#ifdef IPX_F32_TRACE_HITS
+                    compact_query_select(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
+                                         mypub ? mypub + ql : nullptr, nullptr, 0, tr_ph);
+#else
                     compact_query_select(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
                                          mypub ? mypub + ql : nullptr);
+#endif
             }
+            if constexpr ((IPX_F32_OPT & 16) != 0) __builtin_amdgcn_s_setprio(0);
             __syncthreads();
             poll_union_threshold(p, taus, qb, tid);
             issue_stage(p, smem + (g & 1) * STAGE_BYTES, c0.t, qb, c0.ks, wave, lane);
             issue_stage(p, smem + ((g + 1) & 1) * STAGE_BYTES, c1.t, qb, c1.ks, wave, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+#ifdef IPX_F32_TRACE_HITS
+            tr_epi += __builtin_amdgcn_s_memrealtime() - tr_e0;
+#endif
         } else if ((tiles_done & 1) == 0 && is_pow4(tiles_done >> 1)) {
             poll_union_threshold(p, taus, qb, tid);
         }
     }
     };
     switch (nj) {
-        case 4: scan_tiles(std::integral_constant<int, 4>{}); break;
-        case 3: scan_tiles(std::integral_constant<int, 3>{}); break;
-        case 2: scan_tiles(std::integral_constant<int, 2>{}); break;
-        case 1: scan_tiles(std::integral_constant<int, 1>{}); break;
-        default: scan_tiles(std::integral_constant<int, 0>{}); break;
+        case 4:
+            if ((p.nks & 1) == 0) scan_tiles(std::integral_constant<int, 4>{}, std::true_type{});
+            else scan_tiles(std::integral_constant<int, 4>{}, std::false_type{});
+            break;
+        case 3: scan_tiles(std::integral_constant<int, 3>{}, std::false_type{}); break;
+        case 2: scan_tiles(std::integral_constant<int, 2>{}, std::false_type{}); break;
+        case 1: scan_tiles(std::integral_constant<int, 1>{}, std::false_type{}); break;
+        default: scan_tiles(std::integral_constant<int, 0>{}, std::false_type{}); break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tail's dummy copies write LDS too
     __syncthreads();
@@ -1008,6 +1208,12 @@ scan_f32_kernel(const ScanParams p) {
         tr[1] = __builtin_amdgcn_s_memrealtime();
         tr[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
         tr[3] = ((uint64_t)tiles_done << 32) | (uint64_t)n_compact;
+#ifdef IPX_F32_TRACE_HITS
+        tr[2] |= tr_epi << 32;                                             // ticks of 10 ns in episodes
+        tr[0] = tr_ph[0] | (tr_ph[1] << 32);                               // ... of them, wave 0: load | publish
+        tr[1] = tr_ph[2] | (tr_ph[3] << 32);                               //                     k-th | ties + move
+        tr[3] = ((uint64_t)tiles_done << 48) | ((uint64_t)n_compact << 40) | ((uint64_t)(tr_hits & 0xfffff) << 20) | (tr_app & 0xfffff);
+#endif
     }
 }
 
