@@ -289,26 +289,40 @@ template <int QW, int QP> struct HCfg {
 // of 16 KiB (QW 4: 2 rounds per part) or of 4 KiB (QW 1: with one part waves 4..7 repeat the
 // pieces of waves 0..3 — same bytes to the same place — and with two parts every wave has its own
 // piece; either way every wave issues the same number of copies, so one vmcnt count serves all).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"     // m0 on a clobber list (the copy pieces set it themselves)
+// (Round 3: issued from asm in the scalar-base form — M0 = the piece's LDS address, base in scalar registers, the
+// lane's 16 bytes as a 32-bit offset: no per-lane 64-bit address arithmetic in the stage loop.)
 template <int QW, int QP>
 struct StagePieces {
-    const char* ga;     // this lane's 16 bytes of the wave's first A piece
-    const char* gb;     // ... of the wave's first B piece
-    char* la;           // the wave's first A piece in LDS (wave-uniform)
-    char* lb;
+    const char* ga;     // the wave's first A piece (wave-uniform)
+    const char* gb;     // ... first B piece
+    uint32_t la;        // the wave's first A piece in LDS
+    uint32_t lb;
+    uint32_t lane16;
+    static __device__ __forceinline__ const char* uniform_ptr(const char* ptr) {
+        const uint64_t v = (uint64_t)(uintptr_t)ptr;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    }
     __device__ __forceinline__ StagePieces(const ScanParams& p, char* buf, int64_t tile, int qb, int ks, int wave, int lane) {
         using C = HCfg<QW, QP>;
         const int wb = (QW == 4 || QP == 2) ? wave : (wave & 3);
-        ga = (const char*)p.Xp + ((size_t)tile * p.nks + ks) * HSTAGE_A + wave * 1024 + lane * 16;
-        gb = (const char*)p.Qp + ((size_t)qb * p.nks + ks) * C::STAGE_B + wb * 1024 + lane * 16;
-        la = buf + wave * 1024;
-        lb = buf + HSTAGE_A + wb * 1024;
+        ga = uniform_ptr((const char*)p.Xp + ((size_t)tile * p.nks + ks) * HSTAGE_A + wave * 1024);
+        gb = uniform_ptr((const char*)p.Qp + ((size_t)qb * p.nks + ks) * C::STAGE_B + wb * 1024);
+        const uint32_t lbuf = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)buf;
+        la = __builtin_amdgcn_readfirstlane(lbuf + wave * 1024);
+        lb = __builtin_amdgcn_readfirstlane(lbuf + HSTAGE_A + wb * 1024);
+        lane16 = (uint32_t)lane * 16;
     }
     // piece i of HCfg::LOADS: 0, 1 = the A rounds; 2.. = the B rounds (8 KiB apart)
     __device__ __forceinline__ void issue(int i) const {
-        if (i < 2) IPX_GLDS(ga + i * 8192, la + i * 8192);
-        else IPX_GLDS(gb + (i - 2) * 8192, lb + (i - 2) * 8192);
+        const char* g = i < 2 ? ga + i * 8192 : gb + (i - 2) * 8192;
+        const uint32_t l = i < 2 ? la + i * 8192 : lb + (i - 2) * 8192;
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(l), "v"(lane16), "s"(g) : "memory", "m0");
     }
 };
+#pragma clang diagnostic pop
 
 template <int QW, int QP>
 __device__ __forceinline__ void issue_stage_bf16(const ScanParams& p, char* buf, int64_t tile, int qb,
@@ -444,6 +458,9 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
     if (tid < BQ_) {
         cnts[tid] = 0;
         taus[tid] = ((int64_t)qb * BQ_ + tid < p.nq) ? -FLT_MAX : INFINITY;
+#ifdef IPX_SMALL_ABL       // measurement build: only query 0 is live (the others are multiplied and never pass the filter)
+        if (tid >= 1) taus[tid] = INFINITY;
+#endif
     }
     if (tid < 2) flags[tid] = 0;
     const int fill_limit = p.cap - 2 * HBD;
@@ -626,27 +643,38 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
         for (int j = 0; j < QW; ++j) {
             const int ql = wq * (32 * QW) + j * 32 + l31;
             const float tau = lds_read_f32_nodma(&taus[ql]);
-            float m = acc[0][j][0];
+            // the lane's maximum, kept per group of four registers (four consecutive rows): the hit path votes on the
+            // eight groups first, then on the registers of a group somebody passes in (round 3, as in scan_f32_kernel)
+            float g8[8];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+                for (int q4 = 0; q4 < 4; ++q4)
+                    g8[i * 4 + q4] = fmaxf(fmaxf(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1]), fmaxf(acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]));
+            float m = g8[0];
+#pragma unroll
+            for (int u = 1; u < 8; ++u) m = fmaxf(m, g8[u]);
             if (__any(m > tau)) {
                 uint64_t* qu = myqueues + (size_t)ql * p.cap;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float sc = acc[i][j][r];
-                        if (__any(sc > tau)) {
-                            const int64_t doc = docbase + i * 32 + (r & 3) + 8 * (r >> 2);
-                            if (sc > tau && doc < p.N) {
-                                const int pos = lds_atomic_inc_nodma(&cnts[ql]);
-                                if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
-                                else *p.err = 1;
-                                if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
-                                if constexpr (QW == 1) lds_atomic_max_u32_nodma(&best[sub * BQ_ + ql], f32_ordered(sc));
-                                ++tr_appends;
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        if (!__any(g8[i * 4 + q4] > tau)) continue;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * q4 + e;
+                            const float sc = acc[i][j][r];
+                            if (__any(sc > tau)) {
+                                const int64_t doc = docbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                                if (sc > tau && doc < p.N) {
+                                    const int pos = lds_atomic_inc_nodma(&cnts[ql]);
+                                    if (pos < p.cap) qu[pos] = make_key(sc, (uint32_t)doc);
+                                    else *p.err = 1;
+                                    if (pos >= fill_limit) lds_write_i32_nodma(myflag, 1);
+                                    if constexpr (QW == 1) lds_atomic_max_u32_nodma(&best[sub * BQ_ + ql], f32_ordered(sc));
+                                    ++tr_appends;
+                                }
                             }
                         }
                     }
