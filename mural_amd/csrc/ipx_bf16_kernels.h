@@ -522,8 +522,13 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
     // operand registers: A[s] = docs of K-set s (first / last 16 features of the stage); B[x] = a
     // ping-pong pair of query operand sets. At the top of a stage A[0], B[0] hold set 0 (part hi).
     f32x4 A[2][2], B[2][QW];
+    // (small batches with hi + lo parts: B[s] = the hi part of K-set s, BL[s] = its lo part; see TWO_PHASE below)
+    constexpr bool TWO_PHASE = QW == 1 && QP == 2;
+    static_assert(!TWO_PHASE || C::PART_B == 4096, "the lo part's immediate offset below");
+    f32x4 BL[2];
     read_a<QW>(A[0], smem_base + a_off + pc0);
     read_b<QW>(B[0], smem_base + b_off + pc0);
+    if constexpr (TWO_PHASE) IPX_DS_READ_B128(BL[0], smem_base + b_off + pc0, 4096);
 
     int slot = 0, tiles_done = 0;
     // optional trace (ipx_set_param "trace"): wave 0's view of where the time goes
@@ -553,6 +558,23 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
                 mfma_set<QW>(acc, A[0], B[0]);
                 __builtin_amdgcn_sched_barrier(0);
                 wait_ab<QW, 0>(A[1], B[1]);
+            } else if constexpr (TWO_PHASE) {
+                // Small batches, hi + lo parts (round 3): two phases of four MFMAs — (set 0: hi, lo) | (set 1: hi, lo) —
+                // with both parts of a set read together while the other set is multiplied. (Rounds 1-2 ran three
+                // phases of two MFMAs over one ping-pong pair of query registers: 64 MFMA cycles do not cover an LDS
+                // read, and at 64 queries, where the chip holds ~1.6 GHz, the stage chain of ~1190 cycles — not HBM —
+                // set the pace. A 64-query tile has registers to spare.)
+                read_a<QW>(A[1], buf + a_off + pc1);
+                IPX_DS_READ_B128(B[1][0], buf + b_off + pc1, 0);
+                IPX_DS_READ_B128(BL[1], buf + b_off + pc1, 4096);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(B[0][0]), "+v"(BL[0]) :: "memory");
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A[0][0]), as_bf16x8(B[0][0]), acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A[0][1]), as_bf16x8(B[0][0]), acc[1][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A[0][0]), as_bf16x8(BL[0]), acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A[0][1]), as_bf16x8(BL[0]), acc[1][0], 0, 0, 0);
+                pin_acc<QW>(acc);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[1][0]), "+v"(A[1][1]), "+v"(B[1][0]), "+v"(BL[1]) :: "memory");
             } else {
                 // three phases on this stage's buffer: (set 0, lo) | (set 1, hi) | (set 1, lo); each
                 // phase's operands are read while the previous phase is multiplied
@@ -609,6 +631,22 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
                     __builtin_amdgcn_sched_barrier(0);
                     sp.issue(3);
                     if constexpr (QP == 2) sp.issue(5);
+                } else if constexpr (TWO_PHASE) {
+                    IPX_MFMA1(0, 0); IPX_MFMA1(1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_a<QW>(A[0], nbuf + a_off + pc0);
+                    IPX_DS_READ_B128(B[0][0], nbuf + b_off + pc0, 0);
+                    IPX_DS_READ_B128(BL[0], nbuf + b_off + pc0, 4096);
+                    __builtin_amdgcn_sched_barrier(0);
+                    sp.issue(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A[1][0]), as_bf16x8(BL[1]), acc[0][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    sp.issue(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A[1][1]), as_bf16x8(BL[1]), acc[1][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    sp.issue(2);
                 } else {
                     IPX_MFMA1(0, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -743,6 +781,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             // the sort scratch aliases the stage ring: let every copy land, sort, fetch the
             // NBUF stages again (cur[0]'s set-0 operands are already in registers)
             wait_ab<QW, 0>(A[0], B[0]);
+            if constexpr (TWO_PHASE) asm volatile("" : "+v"(BL[0]));       // (the wait above covered its read too)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             uint64_t tr_a = 0, tr_b = 0;
