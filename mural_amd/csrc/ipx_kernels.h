@@ -466,6 +466,11 @@ __device__ __forceinline__ uint32_t nth_largest_regs8(const uint32_t (&x)[8], in
 }
 
 // `aux` / `aux_cap`: the selections' side list; nullptr = the second half of a scratch of 8 bytes per queue slot.
+// REGS: queues of up to 512 entries are selected in registers (nth_largest_regs8). Only the fp32 headline kernel asks
+// for it: its episodes run when the accumulators are dead; in the other kernels the extra live registers cost more than
+// the faster selection brings (scan_f32_small_kernel<2> went from 122 to 136 VGPRs, three waves per SIMD instead of
+// four, and 15 % slower at 64 queries).
+template <bool REGS = false>
 __device__ __forceinline__ void compact_query_select(const ScanParams& p, uint64_t* scratch, int* cnts, float* taus,
                                                      uint64_t* queue, int ql, int lane, uint32_t* pub_slot,
                                                      uint32_t* aux = nullptr, int aux_cap = 0, uint64_t* tph = nullptr) {
@@ -482,7 +487,7 @@ __device__ __forceinline__ void compact_query_select(const ScanParams& p, uint64
     const int kpl8 = (((n + 63) >> 6) + 7) & ~7;         // slots per lane, in batches of 8 (64 * kpl8 <= cap)
     uint32_t* sh = (uint32_t*)scratch;                    // [64 * kpl8] high words, later (in place) the low words of tied keys
     const uint32_t* q32 = (const uint32_t*)queue;
-    if (kpl8 == 8) {
+    if (REGS && kpl8 == 8) {
         // up to 512 entries (every episode of a top-100 search): the high words stay in registers
         uint32_t x[8];
 #pragma unroll
@@ -1149,11 +1154,11 @@ scan_f32_kernel(const ScanParams p) {
             } else {
                 for (int ql = wave; ql < BQ; ql += 4)
 #ifdef IPX_F32_TRACE_HITS
-                    compact_query_select(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
-                                         mypub ? mypub + ql : nullptr, nullptr, 0, tr_ph);
+                    compact_query_select<true>(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
+                                               mypub ? mypub + ql : nullptr, nullptr, 0, tr_ph);
 #else
-                    compact_query_select(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
-                                         mypub ? mypub + ql : nullptr);
+                    compact_query_select<true>(p, scratch, cnts, taus, myqueues + (size_t)ql * p.cap, ql, lane,
+                                               mypub ? mypub + ql : nullptr);
 #endif
             }
             if constexpr ((IPX_F32_OPT & 16) != 0) __builtin_amdgcn_s_setprio(0);
