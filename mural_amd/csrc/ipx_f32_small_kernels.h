@@ -29,33 +29,50 @@ template <int QT> struct SCfg {
 
 // The copy pieces of one stage for one wave: 2 x 1 KiB of its own corpus rows; waves < NBW also
 // one 1-KiB piece of the query stage.
+// (Round 3: issued from asm in the scalar-base form — M0 = the piece's LDS address, base in scalar registers, the lane's
+// 16 bytes as a 32-bit offset: no per-lane 64-bit address arithmetic per stage. At 64 queries this kernel is bound by
+// the fp32 matrix work, and a VALU instruction beside MFMA-streaming waves is not free: DESIGN.md 4.1.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"     // m0 on a clobber list (the copy pieces set it themselves)
 template <int QT>
 struct SmallPieces {
     const char* ga;
     const char* gb;
-    char* la;
-    char* lb;
+    uint32_t la;
+    uint32_t lb;
+    uint32_t lane16;
+    static __device__ __forceinline__ const char* uniform_ptr(const char* ptr) {
+        const uint64_t v = (uint64_t)(uintptr_t)ptr;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    }
     __device__ __forceinline__ SmallPieces(const ScanParams& p, char* slot, int pair, int qb, int ks, int wave, int lane) {
         using C = SCfg<QT>;
         const int th = wave >> 2, wd = wave & 3;
         int64_t tile = (int64_t)pair * 2 + th;
         if (tile >= p.ntiles) tile = p.ntiles - 1;            // odd tile count: the last pair repeats its first tile (rows masked by N)
-        ga = (const char*)p.Xp + ((size_t)tile * p.nks + ks) * STAGE_A_BYTES + wd * 2048 + lane * 16;
-        gb = (const char*)p.Qp + ((size_t)qb * p.nks + ks) * C::STAGE_B + (wave & (C::NBW - 1)) * 1024 + lane * 16;
-        la = slot + th * STAGE_A_BYTES + wd * 2048;
-        lb = slot + C::PAIR_A + (wave & (C::NBW - 1)) * 1024;
+        ga = uniform_ptr((const char*)p.Xp + ((size_t)tile * p.nks + ks) * STAGE_A_BYTES + wd * 2048);
+        gb = uniform_ptr((const char*)p.Qp + ((size_t)qb * p.nks + ks) * C::STAGE_B + (wave & (C::NBW - 1)) * 1024);
+        const uint32_t lslot = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)slot;
+        la = __builtin_amdgcn_readfirstlane(lslot + th * STAGE_A_BYTES + wd * 2048);
+        lb = __builtin_amdgcn_readfirstlane(lslot + C::PAIR_A + (wave & (C::NBW - 1)) * 1024);
+        lane16 = (uint32_t)lane * 16;
     }
-    // With one query block the corpus rows are read once per search: non-temporal (aux bit 1; +1.5 %
-    // measured). With several, the other blocks' workgroups find them in L2: default policy.
+    // With one query block the corpus rows are read once per search: non-temporal (+1.5 % measured). With several,
+    // the other blocks' workgroups find them in L2: default policy.
     __device__ __forceinline__ void issue_a(int i, bool once) const {
+        const char* g = ga + i * 1024;
+        const uint32_t l = la + i * 1024;
         if (once)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + i * 1024),
-                                             (__attribute__((address_space(3))) void*)(la + i * 1024), 16, 0, 2);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2 nt" :: "s"(l), "v"(lane16), "s"(g) : "memory", "m0");
         else
-            IPX_GLDS(ga + i * 1024, la + i * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(l), "v"(lane16), "s"(g) : "memory", "m0");
     }
-    __device__ __forceinline__ void issue_b() const { IPX_GLDS(gb, lb); }
+    __device__ __forceinline__ void issue_b() const {
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lb), "v"(lane16), "s"(gb) : "memory", "m0");
+    }
 };
+#pragma clang diagnostic pop
 
 // s_waitcnt lgkmcnt(N) that the compiler sees as (re)defining the operand registers waited for
 template <int QT, int N>
