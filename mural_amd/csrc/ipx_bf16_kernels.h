@@ -315,6 +315,16 @@ struct StagePieces {
         lb = __builtin_amdgcn_readfirstlane(lbuf + HSTAGE_A + wb * 1024);
         lane16 = (uint32_t)lane * 16;
     }
+    // from the wave's piece addresses of the stage (kept as running pointers by the scan loop)
+    __device__ __forceinline__ StagePieces(const char* ga_, const char* gb_, char* buf, int wave, int lane) {
+        const int wb = (QW == 4 || QP == 2) ? wave : (wave & 3);
+        ga = ga_;
+        gb = gb_;
+        const uint32_t lbuf = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)buf;
+        la = __builtin_amdgcn_readfirstlane(lbuf + wave * 1024);
+        lb = __builtin_amdgcn_readfirstlane(lbuf + HSTAGE_A + wb * 1024);
+        lane16 = (uint32_t)lane * 16;
+    }
     // piece i of HCfg::LOADS: 0, 1 = the A rounds; 2.. = the B rounds (8 KiB apart)
     __device__ __forceinline__ void issue(int i) const {
         const char* g = i < 2 ? ga + i * 8192 : gb + (i - 2) * 8192;
@@ -509,13 +519,35 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
         return c;
     };
 
-    // cur[0] = stage being computed (ring slot `slot`), cur[1..NBUF-1] = in flight, cur[NBUF] = next to issue
-    StageCursor cur[NBUF + 1];
-    cur[0] = StageCursor{split * R, 0, split * R < p.ntiles};
-#pragma unroll
-    for (int i = 1; i <= NBUF; ++i) cur[i] = advance(cur[i - 1]);
-#pragma unroll
-    for (int i = 0; i < NBUF; ++i) issue_stage_bf16<QW, QP>(p, smem + i * STAGE, cur[i].t, qb, cur[i].ks, wave, lane);
+    // c0 = the tile being computed (its first stage in ring slot `slot` at the top of a tile); ci = the next stage to
+    // copy, NBUF stages ahead, with the wave's piece addresses of that stage kept as running pointers: inside a tile a
+    // stage is one constant step further in both operands, so the loop adds instead of multiplying and the cursor's
+    // branches run once per tile (round 3; rounds 1-2 shifted an array of NBUF + 1 cursors every stage).
+    StageCursor c0{split * R, 0, split * R < p.ntiles};
+    StageCursor ci = c0;
+#pragma unroll 1
+    for (int i = 0; i < NBUF; ++i) {
+        issue_stage_bf16<QW, QP>(p, smem + i * STAGE, ci.t, qb, ci.ks, wave, lane);
+        ci = advance(ci);
+    }
+    const char* ga_i;
+    const char* gb_i;
+    auto ci_ptrs = [&]() {
+        const StagePieces<QW, QP> sp0(p, smem, ci.t, qb, ci.ks, wave, lane);
+        ga_i = sp0.ga;
+        gb_i = sp0.gb;
+    };
+    auto step_ci = [&]() {
+        if (ci.ok && ci.ks + 1 < p.nks) {
+            ++ci.ks;
+            ga_i += HSTAGE_A;
+            gb_i += C::STAGE_B;
+        } else {
+            ci = advance(ci);
+            ci_ptrs();
+        }
+    };
+    ci_ptrs();
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 1)) : "memory");
     __syncthreads();
 
@@ -535,8 +567,8 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
     uint64_t tr_epi = 0, tr_sort = 0, tr_begin = 0, tr_w1 = 0, tr_own = 0, tr_w2 = 0;
     uint32_t tr_appends = 0, tr_episodes = 0;
     if (p.trace) tr_begin = __builtin_readcyclecounter();
-    while (cur[0].ok) {
-        const int t = cur[0].t;
+    while (c0.ok) {
+        const int t = c0.t;
         f32x16 acc[2][QW];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -600,7 +632,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             // the addresses of the next copy pieces are worked out before the barrier, and the first
             // MFMAs of the last phase go out right behind it: the matrix core has work queued while
             // this wave issues the next stage's operand reads
-            const StagePieces<QW, QP> sp(p, smem + slot * STAGE, cur[NBUF].t, qb, cur[NBUF].ks, wave, lane);
+            const StagePieces<QW, QP> sp(ga_i, gb_i, smem + slot * STAGE, wave, lane);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
             __builtin_amdgcn_s_barrier();
@@ -663,11 +695,11 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
                 __builtin_amdgcn_sched_barrier(0);
 #undef IPX_MFMA1
             }
-#pragma unroll
-            for (int i = 0; i < NBUF; ++i) cur[i] = cur[i + 1];
-            cur[NBUF] = advance(cur[NBUF]);
+            step_ci();
             slot = nslot;
         }
+        c0.ks = p.nks - 1;          // the tile is done: on to the cursor's next tile
+        c0 = advance(c0);
 
         // ---- epilogue: threshold filter, rare append to the per-query queues ----
         ++tiles_done;
@@ -779,7 +811,7 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
         if (episode) {
             ++tr_episodes;
             // the sort scratch aliases the stage ring: let every copy land, sort, fetch the
-            // NBUF stages again (cur[0]'s set-0 operands are already in registers)
+            // NBUF stages again (c0's set-0 operands are already in registers)
             wait_ab<QW, 0>(A[0], B[0]);
             if constexpr (TWO_PHASE) asm volatile("" : "+v"(BL[0]));       // (the wait above covered its read too)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -795,10 +827,12 @@ scan_bf16_kernel(const ScanParams p, const int nsortwaves) {
             __syncthreads();
             if (p.trace) tr_w2 += __builtin_readcyclecounter() - tr_b;
             if (!fast1 && tid < BQ_) poll_union_threshold_n<BQ_>(p, taus, qb, tid);
-#pragma unroll
+            StageCursor cr = c0;
+#pragma unroll 1
             for (int i = 0; i < NBUF; ++i) {
                 const int sl = slot + i < NBUF ? slot + i : slot + i - NBUF;
-                issue_stage_bf16<QW, QP>(p, smem + sl * STAGE, cur[i].t, qb, cur[i].ks, wave, lane);
+                issue_stage_bf16<QW, QP>(p, smem + sl * STAGE, cr.t, qb, cr.ks, wave, lane);
+                cr = advance(cr);
             }
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 1)) : "memory");
             __syncthreads();

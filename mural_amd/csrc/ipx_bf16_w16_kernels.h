@@ -45,6 +45,13 @@ struct WPieces {
         la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)buf + wave * 1024);
         lane16 = (uint32_t)lane * 16;
     }
+    // from the wave's piece addresses of the stage (kept as running pointers by the scan loop)
+    __device__ __forceinline__ WPieces(const char* ga_, const char* gb_, char* buf, int wave, int lane) {
+        ga = ga_;
+        gb = gb_;
+        la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)buf + wave * 1024);
+        lane16 = (uint32_t)lane * 16;
+    }
     template <bool NT_>
     static __device__ __forceinline__ void piece(const char* g, uint32_t l, uint32_t voff) {
         if constexpr (NT_)
@@ -151,6 +158,26 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
         WPieces<QP, NT>(p, smem + i * STAGE, wi.t, qb, wi.ks, wave, lane).issue_all();
         advance(wi);
     }
+    // The stage to copy next (wi), as the wave's piece addresses: inside a tile a stage is one constant step further in
+    // both operands, so the loop adds instead of multiplying, and the walker's branches run once per tile, not per stage
+    // (round 3: what a wave pays per stage beside MFMA-streaming waves is its NUMBER of instructions).
+    const char* ga_i;
+    const char* gb_i;
+    auto wi_ptrs = [&]() {
+        ga_i = WPieces<QP, NT>::uniform_ptr((const char*)p.Xp + ((size_t)wi.t * p.nks + wi.ks) * HSTAGE_A + wave * 1024);
+        gb_i = WPieces<QP, NT>::uniform_ptr((const char*)p.Qp + ((size_t)qb * p.nks + wi.ks) * (C::PART_B * QP) + wave * 1024);
+    };
+    auto step_wi = [&]() {
+        if (wi.ok && wi.ks + 1 < p.nks) {
+            ++wi.ks;
+            ga_i += HSTAGE_A;
+            gb_i += C::PART_B * QP;
+        } else {
+            advance(wi);
+            wi_ptrs();
+        }
+    };
+    wi_ptrs();
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 1)) : "memory");
     __syncthreads();
 
@@ -199,7 +226,7 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
                 if constexpr (QP == 2) {
                     IPX_DS_READ_B128(c0, buf + b_off + C::PART_B + pc1, 0); IPX_DS_READ_B128(c1, buf + b_off + C::PART_B + pc1, 2048);
                 }
-                const WPieces<QP, NT> sp(p, smem + slot * STAGE, wi.t, qb, wi.ks, wave, lane);
+                const WPieces<QP, NT> sp(ga_i, gb_i, smem + slot * STAGE, wave, lane);
                 if constexpr (QP == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1) :: "memory");
                 else w16_wait4(a0, a1, b0, b1);
                 // this wave's last reads of the slot are in registers; its pieces of the next stage have landed
@@ -231,10 +258,11 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
                     sp.issue_all();
                 }
                 asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
-                advance(wi);
-                advance(w0);
+                step_wi();
                 slot = nslot;
             }
+            w0.ks = p.nks - 1;          // the tile is done: on to the walker's next tile
+            advance(w0);
 
             // ---- epilogue: threshold filter, rare append to the per-query queues ----
             ++tiles_done;
@@ -312,7 +340,7 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
                 IPX_W16_ROW(1, b1);
                 __builtin_amdgcn_sched_barrier(0);
                 IPX_DS_READ_B128(b0, buf + b16, 2048); IPX_DS_READ_B128(b1, buf + b16, 3072);
-                const WPieces<QP, NT> sp(p, smem + slot * STAGE, wi.t, qb, wi.ks, wave, lane);
+                const WPieces<QP, NT> sp(ga_i, gb_i, smem + slot * STAGE, wave, lane);
                 w16_wait2(b0, b1);
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NBUF - 2)) : "memory");
                 __builtin_amdgcn_s_barrier();
@@ -321,10 +349,11 @@ scan_bf16_w16_kernel(const ScanParams p, const int nsortwaves) {
                 IPX_W16_ROW(2, b0);
                 IPX_W16_ROW(3, b1);
                 __builtin_amdgcn_sched_barrier(0);
-                advance(wi);
-                advance(w0);
+                step_wi();
                 slot = nslot;
             }
+            w0.ks = p.nks - 1;          // the tile is done: on to the walker's next tile
+            advance(w0);
 #undef IPX_W16_ROW
             ++tiles_done;
             if (p.trace) tr_e0 = __builtin_readcyclecounter();

@@ -58,6 +58,17 @@ struct SmallPieces {
         lb = __builtin_amdgcn_readfirstlane(lslot + C::PAIR_A + (wave & (C::NBW - 1)) * 1024);
         lane16 = (uint32_t)lane * 16;
     }
+    // from the wave's piece addresses of the stage (kept as running pointers by the scan loop)
+    __device__ __forceinline__ SmallPieces(const char* ga_, const char* gb_, char* slot, int wave, int lane) {
+        using C = SCfg<QT>;
+        const int th = wave >> 2, wd = wave & 3;
+        ga = ga_;
+        gb = gb_;
+        const uint32_t lslot = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)slot;
+        la = __builtin_amdgcn_readfirstlane(lslot + th * STAGE_A_BYTES + wd * 2048);
+        lb = __builtin_amdgcn_readfirstlane(lslot + C::PAIR_A + (wave & (C::NBW - 1)) * 1024);
+        lane16 = (uint32_t)lane * 16;
+    }
     // With one query block the corpus rows are read once per search: non-temporal (+1.5 % measured). With several,
     // the other blocks' workgroups find them in L2: default policy.
     __device__ __forceinline__ void issue_a(int i, bool once) const {
@@ -188,6 +199,26 @@ scan_f32_small_kernel(const ScanParams p, const int nsortwaves) {
     }
     wait_newest(std::integral_constant<int, NBUF - 1>{});
     __syncthreads();
+    // The stage to copy next (wi), as the wave's piece addresses: inside a tile pair a stage is one constant step further
+    // in both operands, so the loop adds instead of multiplying, and the walker's branches run once per pair.
+    const char* ga_i;
+    const char* gb_i;
+    auto wi_ptrs = [&]() {
+        const SmallPieces<QT> sp(p, smem, wi.t, qb, wi.ks, wave, lane);
+        ga_i = sp.ga;
+        gb_i = sp.gb;
+    };
+    auto step_wi = [&]() {
+        if (wi.ok && wi.ks + 1 < p.nks) {
+            ++wi.ks;
+            ga_i += STAGE_A_BYTES;
+            gb_i += C::STAGE_B;
+        } else {
+            advance(wi);
+            wi_ptrs();
+        }
+    };
+    wi_ptrs();
 
     // operand registers: set 0 = features 0..7 of the stage, set 1 = features 8..15; lane (l31, h)
     // holds features 4h..4h+3 of its row in each: the MFMA order inside an 8-feature group is
@@ -223,7 +254,7 @@ scan_f32_small_kernel(const ScanParams p, const int nsortwaves) {
             // this stage's last operands are in registers; the next stage's pieces of this wave
             // have landed (NBUF - 2 younger stages may be in flight); after the barrier both hold
             // for every wave of the workgroup
-            const SmallPieces<QT> sp(p, smem + slot * STAGE, wi.t, qb, wi.ks, wave, lane);
+            const SmallPieces<QT> sp(ga_i, gb_i, smem + slot * STAGE, wave, lane);
             __builtin_amdgcn_sched_barrier(0);
             wait_newest(std::integral_constant<int, NBUF - 2>{});
             __builtin_amdgcn_s_barrier();
@@ -240,10 +271,11 @@ scan_f32_small_kernel(const ScanParams p, const int nsortwaves) {
             if (copies_b) sp.issue_b();
             __builtin_amdgcn_sched_barrier(0);
             IPX_M(a1, b1, 3);
-            advance(wi);
-            advance(w0);
+            step_wi();
             slot = nslot;
         }
+        w0.ks = p.nks - 1;          // the pair is done: on to the walker's next pair
+        advance(w0);
 #undef IPX_M
 
         // ---- epilogue: threshold filter, rare append to the per-query queues ----
