@@ -377,12 +377,19 @@ def main():
     if world == 1:
         # one rank: a 1-rank NCCL group on a free port, so the cfg5 measurement runs its all-gather through RCCL; if
         # that cannot be set up the run goes on without a group (the exchange then is the merge alone)
+        import datetime
         import socket
-        with socket.socket() as sock:
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
         try:
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            if "TORCHELASTIC_RUN_ID" in os.environ or "MASTER_PORT" in os.environ:
+                # launched by torch.distributed.run with one rank: its agent holds the store, a tcp:// rendezvous of our
+                # own would wait for a server that nobody starts
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
+            else:
+                with socket.socket() as sock:
+                    sock.bind(("127.0.0.1", 0))
+                    port = sock.getsockname()[1]
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev,
+                                        timeout=datetime.timedelta(seconds=120))
         except Exception as exc:      # noqa: BLE001 - any failure here only removes the 1-rank collective
             print(f"bench: no 1-rank process group ({exc}); continuing without", file=sys.stderr, flush=True)
     else:

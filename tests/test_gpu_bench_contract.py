@@ -70,3 +70,21 @@ def test_cfg5_line():
         assert r["ms_per_search"] > 0 and r["scan_ms"] > 0 and r["ms_per_search"] >= r["scan_ms"] * 0.9
         assert abs(r["roofline"]["achieved"] - 600000 * 768 * 2 / (r["scan_ms"] * 1e-3) / 1e9) <= 1e-6 * r["roofline"]["achieved"]
     assert abs(j["value"] - rows[-1]["queries_per_s"]) <= 1e-9 * j["value"]
+
+
+def test_bench_under_torch_distributed_run_with_one_rank():
+    """The driver launches N > 1 ranks with torch.distributed.run; the same launcher with ONE rank must work too (the
+    1-rank group then comes from the launcher's store: a tcp:// rendezvous of bench.py's own used to wait forever for a
+    server that nobody starts — found late in round 3)."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--rows", "300000", "--queries", "300", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 1 and j["value"] > 0 and j["roofline"]["bound"] == "mfma"
