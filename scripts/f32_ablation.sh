@@ -2,6 +2,7 @@
 # A/B builds of the fp32 headline scan (ipx_kernels.h): ablations (IPX_F32_ABL=N, results wrong, timing only: what each
 # part of the stage costs) and optimisation switches (IPX_F32_OPT=N, same bits).
 #   bash scripts/f32_ablation.sh build "abl2 abl32 opt0 opt1"     # here (CPU): mural_amd/libipx_<name>.so
+#   bash scripts/f32_ablation.sh build trace                       # the counting build for scripts/trace_f32_hits.py
 #   gpurun -- 'bash scripts/f32_ablation.sh run "abl2 abl32 opt0 opt1"'
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -12,6 +13,7 @@ if [ "$MODE" = build ]; then
         case $n in
             abl*) D="-DIPX_F32_ABL=${n#abl}" ;;
             opt*) D="-DIPX_F32_OPT=${n#opt}" ;;
+            trace) D="-DIPX_F32_TRACE_HITS" ;;          # libipx_trace.so: what scripts/trace_f32_hits.py loads
         esac
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -pthread $D \
             $R/mural_amd/csrc/ipx.hip $R/mural_amd/csrc/ranking_writer.cpp -o $R/mural_amd/libipx_$n.so &
