@@ -280,6 +280,28 @@ def _assign_files(rows_per_file, world):
     return owner
 
 
+class _RankFailure:
+    """What a rank tells the others when a load step failed on it (picklable: rank + the error's text)."""
+
+    def __init__(self, rank, error):
+        self.rank, self.text = rank, f"{type(error).__name__}: {error}"
+
+    def __str__(self):
+        return f"rank {self.rank} failed while loading: {self.text}"
+
+
+def _raise_together(dist, rank, world, failure):
+    """All ranks exchange whether their load step failed; if any did, every rank raises (the failing ones their
+    own exception, the others a RuntimeError naming the first failing rank), so no rank is left in a collective."""
+    said = [None] * world
+    dist.all_gather_object(said, _RankFailure(rank, failure) if failure is not None else None)
+    if failure is not None:
+        raise failure
+    for s in said:
+        if s is not None:
+            raise RuntimeError(str(s))
+
+
 def _main_sharded(args, engine_factory=None):
     """`python -m torch.distributed.run --nproc-per-node G -m tevatron.faiss_retriever ...`: one process
     per GPU, the shard files dealt to the ranks in contiguous groups, every rank searches all queries on its
@@ -306,29 +328,41 @@ def _main_sharded(args, engine_factory=None):
             dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         # rank 0 reads every shard's ids; the rows themselves are mapped, not read (pickle_load)
-        meta, look_up = [None], []
+        # a rank that fails while the others wait in a collective would leave them there until the launcher's
+        # timeout: every load step below ends in an exchange of its outcome, so all ranks raise together and the
+        # message names the rank and the error (the reference, one process, just raises: __main__.py:74-80)
+        meta, look_up, failure = [None], [], None
         if rank == 0:
-            rows, dim = [], None
-            for f in index_files:
-                reps, lookup = pickle_load(f)
-                rows.append(int(reps.shape[0]))
-                dim = int(reps.shape[1]) if dim is None else dim
-                look_up += lookup
-            meta = [(rows, dim)]
+            try:
+                rows, dim = [], None
+                for f in index_files:
+                    reps, lookup = pickle_load(f)
+                    rows.append(int(reps.shape[0]))
+                    dim = int(reps.shape[1]) if dim is None else dim
+                    look_up += lookup
+                meta = [(rows, dim)]
+            except Exception as e:                       # noqa: BLE001 (re-raised below, on every rank)
+                failure, meta = e, [_RankFailure(0, e)]
         dist.broadcast_object_list(meta, src=0)
+        if isinstance(meta[0], _RankFailure):
+            raise failure if failure is not None else RuntimeError(str(meta[0]))
         rows, dim = meta[0]
         owner = _assign_files(rows, world)
         starts = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
         mine = [i for i, r in enumerate(owner) if r == rank]
         row_lo = int(starts[mine[0]]) if mine else int(starts[-1])
-        index = ShardedFlatIP(dim, row_lo=row_lo, device=None if engine_factory else local,
-                              engine=engine_factory(dim) if engine_factory else None)
-        for i in mine:
-            p_reps, _ = pickle_load(index_files[i])
-            index.add_local(p_reps if p_reps.dtype == np.float16 else p_reps.astype('float32', copy=False))
+        try:
+            index = ShardedFlatIP(dim, row_lo=row_lo, device=None if engine_factory else local,
+                                  engine=engine_factory(dim) if engine_factory else None)
+            for i in mine:
+                p_reps, _ = pickle_load(index_files[i])
+                index.add_local(p_reps if p_reps.dtype == np.float16 else p_reps.astype('float32', copy=False))
 
-        q_reps, q_lookup = pickle_load(args.query_reps)
-        q_reps = q_reps.astype('float32')
+            q_reps, q_lookup = pickle_load(args.query_reps)
+            q_reps = q_reps.astype('float32')
+        except Exception as e:                           # noqa: BLE001
+            failure = e
+        _raise_together(dist, rank, world, failure)
         table = _lookup_blob_async(look_up) if rank == 0 and args.save_text and look_up else None
         logger.info('Index Search Start')
         # chunking never changes a result here (a score does not depend on its batch): large chunks

@@ -174,6 +174,43 @@ def test_cli_under_torchrun_equals_single_process_output(tmp_path, world, nfiles
     assert len((tmp_path / "rank.tsv").read_bytes().splitlines()) == nq * depth
 
 
+def _failing_cli_worker(rank, world, port, tmp, out):
+    """Runs the sharded CLI on broken input and records how this rank's call ended."""
+    try:
+        _cli_worker(rank, world, port, tmp, 5)
+        said = "finished"
+    except BaseException as e:                               # noqa: BLE001
+        said = f"{type(e).__name__}: {e}"
+    with open(os.path.join(out, f"rank{rank}.txt"), "w") as f:
+        f.write(said)
+
+
+@pytest.mark.parametrize("broken", ["shard", "queries"])
+def test_cli_ranks_raise_together_when_a_load_fails(tmp_path, broken):
+    """A rank whose load step fails must not leave the others in a collective: with a shard
+    file rank 0 cannot unpickle, or a query file no rank can, every rank's call ends with an error promptly."""
+    import pickle
+    import time
+    d = 16
+    rng = np.random.default_rng(3)
+    for i, n in enumerate([30, 41]):
+        with open(tmp_path / f"corpus_emb{i}.pkl", "wb") as f:
+            pickle.dump((rng.standard_normal((n, d), dtype=np.float32), [f"D{i}_{j}" for j in range(n)]), f)
+    with open(tmp_path / "q.pkl", "wb") as f:
+        pickle.dump((rng.standard_normal((4, d), dtype=np.float32), ["1", "2", "3", "4"]), f)
+    (tmp_path / ("corpus_emb1.pkl" if broken == "shard" else "q.pkl")).write_bytes(b"not a pickle")
+    out = tmp_path / "said"
+    out.mkdir()
+    t0 = time.monotonic()
+    mp.spawn(_failing_cli_worker, args=(2, _free_port(), str(tmp_path), str(out)), nprocs=2, join=True)
+    assert time.monotonic() - t0 < 60
+    said = [(out / f"rank{r}.txt").read_text() for r in range(2)]
+    assert all(s != "finished" for s in said), said
+    if broken == "shard":                                     # rank 0 read the ids: its own error; rank 1 is told
+        assert "rank 0 failed while loading" in said[1], said
+    assert not (tmp_path / "rank.tsv").exists()
+
+
 def test_one_command_spawns_the_ranks(tmp_path, monkeypatch):
     """IPX_GPUS=N: the plain CLI command starts N rank processes itself (mural_amd/faiss_retriever/__main__.py::
     _spawn_ranks) — here 2 ranks over gloo with the oracle engine injected through the rank command — and the
