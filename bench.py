@@ -368,6 +368,14 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("IPX_BENCH_WATCHDOG"):
+        # a run that is still going after this many seconds prints every thread's Python stack to stderr and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["IPX_BENCH_WATCHDOG"]), exit=True)
+
+    def stage(msg):
+        """Progress on stderr (the JSON line owns stdout): where a run that stops has got to."""
+        print(f"bench[{rank}/{world}] {time.strftime('%H:%M:%S')} {msg}", file=sys.stderr, flush=True)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -434,6 +442,7 @@ def main():
             sample.append(part[: args.cpu_sample_rows - sum(x.shape[0] for x in sample)].cpu().numpy())
         torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
+    stage(f"index built: rows [{lo}, {hi}) in {t_build:.1f} s")
     g = torch.Generator(device=dev)
     g.manual_seed(4321)
     Q = torch.randn((nq, d), generator=g, device=dev, dtype=torch.float32)
@@ -474,6 +483,7 @@ def main():
         ix.set_param("f32_scan", 1)
     elapsed, scan_ms, D, I = timed(Q, args.steps, args.warmup)
     ms_per_step = elapsed * 1e3 / args.steps
+    stage(f"headline timed: {ms_per_step:.2f} ms per step")
     assert int(I.min()) >= 0 and int(I.max()) < n and bool((D[:, :-1] >= D[:, 1:]).all())
     geo, bf, tm = ix.last_geometry(), ix.last_bf16_stats(), ix.last_timing()
     is_bf16 = bf["candidates"] > 0
@@ -559,7 +569,9 @@ def main():
             extra["norm_spread"] = run_norm_spread(torch, dev, d, rows=int(1_000_000 * sc), nq=nq)
     if not args.no_extras and full:
         # BASELINE.json configs[4] (its own shard per rank, weak scaling), any number of ranks
+        stage("cfg5 shard")
         extra["cfg5"] = run_cfg5(torch, dist, dev, local_rank, rank, world, d, 100, args.cfg5_rows)
+        stage("cfg5 done")
 
     if rank == 0:
         scan_avg = sum(scan_ms) / len(scan_ms)

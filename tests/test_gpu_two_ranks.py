@@ -1,9 +1,12 @@
-"""Two rank PROCESSES on the one GPU of this box, each with the HIP engine (libipx.so) on its own row shard, the
-collectives over gloo on device tensors: everything of the N-GPU path (mural_amd/sharded.py, __main__._main_sharded:
-per-rank id base, packed exchange blocks written by the search, all-gather, ipx_merge_topk_packed / ipx_merge_topk on
-every rank, rank 0 writing the ranking) except RCCL's transport, which needs a second GPU (tests/test_zy_multi_gpu.py).
-Replaces the reference's per-shard runs + reducer (docs/retrieval.md:31-53, faiss_retriever/reducer.py:10-20); results
-are compared bit for bit with the oracle's single-index answer and with the single-process CLI's bytes."""
+"""Two and three rank PROCESSES on the one GPU of this box, each with the HIP engine (libipx.so) on its own row shard:
+the N-GPU path (mural_amd/sharded.py, __main__._main_sharded: per-rank id base, the packed exchange block, all-gather,
+ipx_merge_topk_packed / ipx_merge_topk on every rank, rank 0 writing the ranking) with real engines in real rank
+processes. The exchange blocks are staged through host memory and gathered by gloo there (HostStagedHipEngine): RCCL
+needs one GPU per rank (tests/test_zy_multi_gpu.py), and gloo's own device-tensor path stalled for seconds to for ever
+when two processes kept one GPU busy — a property of that combination, not of the engine, but no
+basis for a test. Replaces the reference's per-shard runs + reducer (docs/retrieval.md:31-53,
+faiss_retriever/reducer.py:10-20); results are compared bit for bit with the oracle's single-index answer and with the
+single-process CLI's bytes."""
 import os
 import socket
 import sys
@@ -32,6 +35,45 @@ def _data():
     return rng.standard_normal((N, DIM), dtype=np.float32), rng.standard_normal((NQ, DIM), dtype=np.float32)
 
 
+class HostStagedHipEngine:
+    """The product's _HipEngine (mural_amd/sharded.py) on GPU 0, presenting its results and exchange blocks in host
+    memory, so that ShardedFlatIP's collectives run on CPU tensors."""
+
+    def __init__(self, d, storage=None):
+        from mural_amd.sharded import _HipEngine
+        self.e = _HipEngine(d, 0, storage)
+
+    def set_id_base(self, base):
+        self.e.set_id_base(base)
+
+    def add(self, x):
+        self.e.add(x)
+
+    def out_device(self):
+        import torch
+        return torch.device("cpu")
+
+    def packed_block_bytes(self, nq, k):
+        return self.e.packed_block_bytes(nq, k)
+
+    def search(self, q, k, out=None):
+        import torch
+        D, I = self.e.search(torch.as_tensor(q).cuda(), k)
+        if out is None:
+            return D.cpu(), I.cpu()
+        out[0].copy_(D)
+        out[1].copy_(I)
+        return out
+
+    def merge_packed(self, blocks, S, nq, k, k_out):
+        oD, oI = self.e.merge_packed(blocks.cuda(), S, nq, k, k_out)
+        return oD.cpu(), oI.cpu()
+
+    def merge(self, D, I, k_out):
+        oD, oI = self.e.merge(D.cuda(), I.cuda(), k_out)
+        return oD.cpu(), oI.cpu()
+
+
 def _group(rank, world, port):
     import torch
     import torch.distributed as dist
@@ -47,16 +89,16 @@ def _search_worker(rank, world, port, out_dir, storage):
     from mural_amd.sharded import ShardedFlatIP, shard_bounds
     X, Q = _data()
     lo, hi = shard_bounds(N, world, rank)
-    index = ShardedFlatIP(DIM, row_lo=lo, device=0, storage=storage)
+    index = ShardedFlatIP(DIM, row_lo=lo, engine=HostStagedHipEngine(DIM, storage))
     half = (hi - lo) // 2                       # two adds: host rows, then device rows
     index.add_local(X[lo:lo + half])
     index.add_local(torch.from_numpy(X[lo + half:hi]).cuda())
-    Qd = torch.from_numpy(Q).cuda()
+    Qh = torch.from_numpy(Q)
     for k in DEPTHS:
-        D, I = index.search(Qd, k)
+        D, I = index.search(Qh, k)
         np.save(os.path.join(out_dir, f"D_{rank}_{k}.npy"), D.cpu().numpy())
         np.save(os.path.join(out_dir, f"I_{rank}_{k}.npy"), I.cpu().numpy())
-    D, I = index.search(Q[:1], 5)               # one host query: the latency-shaped exchange
+    D, I = index.search(Q[:1], 5)               # one query: the latency-shaped exchange
     np.save(os.path.join(out_dir, f"D_{rank}_one.npy"), D.cpu().numpy())
     np.save(os.path.join(out_dir, f"I_{rank}_one.npy"), I.cpu().numpy())
     dist.barrier()
@@ -86,7 +128,7 @@ def test_rank_processes_with_hip_engines_return_the_single_index_result(tmp_path
 def _cli_worker(rank, world, port, argv):
     torch, dist = _group(rank, world, port)
     from mural_amd.faiss_retriever import __main__ as drv
-    drv._main_sharded(drv._parse_args(argv))    # the group exists: the CLI uses it, HIP engines on cuda:0
+    drv._main_sharded(drv._parse_args(argv), engine_factory=HostStagedHipEngine)    # the group exists: the CLI uses it
     dist.destroy_process_group()
 
 
