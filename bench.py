@@ -14,7 +14,9 @@ its shard, the (score, id) candidates are all-gathered over RCCL and merged on t
 corpus), batches of 1..64 queries, each search timed end to end INCLUDING the candidate exchange (one RCCL
 all-gather) and the merge. With one rank the collective runs on a 1-rank NCCL group.
 
-Rank 0 prints ONE JSON line; see DESIGN.md §Measurement for the roofline arithmetic.
+Rank 0 prints ONE JSON line on stdout; see DESIGN.md §Measurement for the roofline arithmetic. Every rank writes a
+line per stage to stderr (index built / headline timed / cfg5); `IPX_BENCH_WATCHDOG=<seconds>` makes a run that is
+still going after that long print every thread's Python stack and exit.
 """
 import hashlib
 import argparse
